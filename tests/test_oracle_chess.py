@@ -1,0 +1,59 @@
+"""Pin the oracle's reader + renderer on the reference's only data fixture:
+data/chess.maray -> images/chess.png (README.md:4-6).
+
+The PNG is NOT bit-reproducible from the file (156 of 1,048,576
+pixels differ, all on rows 512 and 704 where a step() argument is ~1e-14 from
+zero), so the gate is >= 99.98 % and "mismatches only on those two rows".
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+from PIL import Image
+
+from conftest import GOLDEN
+from oracle_ffi import Scene
+
+TAGS = ['Arc', 'X', 'Y', 'Tau', 'E', 'Var', 'Nat', 'Neg', 'Abs', 'Recip', 'Sqrt', 'Step',
+        'Sin', 'Exp', 'Ln', 'Add', 'Mul', 'Max', 'Min', 'Let', 'Decor', 'App']
+
+
+def test_reader_consumes_chess_exactly(chess_bytes):
+    assert len(chess_bytes) == 634016
+    s = Scene(chess_bytes)
+    assert s.size == (1024, 1024)
+    assert s.legacy
+    for c in range(3):
+        assert s.node_count(c) == 29314
+        h = dict(zip(TAGS, s.tag_histogram(c)))
+        assert {k: v for k, v in h.items() if v} == {
+            'Mul': 6243, 'Add': 3366, 'Recip': 2982, 'Neg': 2467, 'Step': 1482, 'Min': 768, 'Sin': 256,
+            'Max': 256, 'Nat': 7381, 'Var': 3519, 'X': 329, 'Y': 8, 'Tau': 256, 'Let': 1}
+
+
+def test_chess_band_matches_png_off_the_edge_rows(chess_bytes):
+    """Quick band (rows 96..128 contain board pixels) — exact match expected."""
+    png = np.asarray(Image.open(os.path.join(GOLDEN, 'chess.png')).convert('RGB'))
+    s = Scene(chess_bytes)
+    rgb8, _ = s.render_rows(1024, 1024, 600, 616)
+    assert np.array_equal(rgb8, png[600:616])
+
+
+def test_chess_full_image_vs_png_and_golden_hash(chess_bytes):
+    png = np.asarray(Image.open(os.path.join(GOLDEN, 'chess.png')).convert('RGB'))
+    s = Scene(chess_bytes)
+    rgb8, rgb64 = s.render_rows(1024, 1024, 0, 1024)
+    assert set(np.unique(rgb8)) <= {0, 255}
+    diff = np.any(rgb8 != png, axis=2)
+    n = int(diff.sum())
+    assert n <= 0.0002 * 1024 * 1024          # >= 99.98 % equal
+    rows = set(np.nonzero(diff.any(axis=1))[0].tolist())
+    assert rows <= {512, 704}
+    with open(os.path.join(GOLDEN, 'chess_1024.json')) as f:
+        g = json.load(f)
+    assert n == g['png_mismatch_pixels']
+    assert int((rgb8[:, :, 0] == 255).sum()) == g['white_pixels']
+    assert hashlib.sha256(rgb8.tobytes()).hexdigest() == g['rgb8_sha256']
+    # f64 plane: values are exactly 0.0 or 255.0
+    assert set(np.unique(rgb64)) <= {0.0, 255.0}
