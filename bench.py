@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py — Mpixels/s of the MI355X evaluator on chess.maray @ 4096x4096.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
+is launched under torch.distributed.run with one rank per GPU.  A "step" is one
+pass of the hot path over the rank's whole tile (4096 x 4096 pixels), outputs
+resident in HBM.  Pixels are independent, so ranks own disjoint row tiles and no
+data-path collective is issued (weak scaling: per-GPU work is fixed); the only
+collectives are the timing barrier and the max-over-ranks of the elapsed time.
+
+Rank 0 prints ONE JSON line with the metric, the roofline of the dominant kernel
+(live HIP-event timing on the launch stream) and, at N = 1, the CPU baseline
+(the oracle = restatement of the reference's Rayon interpreter, timed on a
+bounded sample of the same workload on this host's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_OPS_PER_PIXEL = 10241          # 10,239 unique non-constant ops + the two rescale muls
+PEAK_F64_TOPS = 39.3               # MI355X f64 VALU, non-FMA instr/s: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+W = 4096
+H_TILE = 4096
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--backend', default=os.environ.get('MARAY_BENCH_BACKEND', 'auto'))
+    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='CPU baseline sample budget (0 = skip)')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import maray_amd as M
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a MI355X: no HIP device is visible (there is no CPU fallback)')
+    torch.cuda.set_device(local)
+    n_gpus = world
+
+    data = open(os.path.join(ROOT, 'tests', 'golden', 'chess.maray'), 'rb').read()
+    scene = M.Scene(data)
+    scene.rescale(4, 4)                      # config 3: chess.maray regenerated at 4096 x 4096 (exact power-of-two rescale)
+    tape = scene.lower()
+    h_total = H_TILE * n_gpus
+    y0, y1 = rank * H_TILE, (rank + 1) * H_TILE
+
+    backends = {'tape': M.BACKEND_TAPE, 'tape-smem': M.BACKEND_TAPE_SMEM, 'jit': M.BACKEND_JIT}
+    order = ['jit', 'tape-smem', 'tape'] if args.backend == 'auto' else [args.backend]
+    ctx = None
+    for name in order:
+        try:
+            ctx = M.Context(tape, device=local, backend=backends[name])
+            backend_name = name
+            break
+        except M.MarayError as e:
+            if args.backend != 'auto':
+                raise
+            last = e
+    if ctx is None:
+        raise last
+
+    out8 = torch.empty((H_TILE, W, 3), dtype=torch.uint8, device='cuda')
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.render_rows_device(W, h_total, y0, y1, d_rgb8=out8.data_ptr(), stream=stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    px_per_step = W * H_TILE * n_gpus
+    value = px_per_step * args.steps / dt / 1e6
+
+    # roofline of the dominant (pixel) kernel: HIP events on the launch stream, this rank's tile
+    k_ms = ctx.time_rows(W, h_total, y0, y1, d_rgb8=out8.data_ptr(), reps=max(3, min(args.steps, 10)))
+    ops_per_launch = ALG_OPS_PER_PIXEL * W * H_TILE
+    achieved = ops_per_launch / (k_ms * 1e-3) / 1e12
+    hbm_gbs = (W * H_TILE * 3) / (k_ms * 1e-3) / 1e9
+
+    # parity spot check of the timed output against the committed golden (every 4th pixel of rows 0..4095 = config 1)
+    parity = None
+    if rank == 0:
+        import hashlib
+        g = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'chess_1024.json')))
+        sub = out8[::4, ::4].contiguous().cpu().numpy()
+        parity = hashlib.sha256(sub.tobytes()).hexdigest() == g['rgb8_sha256']
+
+    cpu = None
+    if rank == 0 and n_gpus == 1 and args.cpu_seconds > 0:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        from oracle_ffi import Scene as OScene
+        o = OScene(scene.encode())
+        threads = os.cpu_count() or 1
+        t = time.perf_counter()
+        o.render_rows(W, H_TILE, 2048, 2048 + 2, threads=threads, want_f64=False)   # pilot: 2 rows
+        pilot = time.perf_counter() - t
+        rows = int(max(threads, min(H_TILE - 2048, args.cpu_seconds / max(pilot / 2, 1e-6))))
+        t = time.perf_counter()
+        o.render_rows(W, H_TILE, 2048, 2048 + rows, threads=threads, want_f64=False)
+        ct = time.perf_counter() - t
+        cpu = {'value': W * rows / ct / 1e6, 'unit': 'Mpixels/s', 'cores': threads, 'kind': 'port',
+               'sample': '%d rows x %d px of the same 4096x4096 chess scene (rows 2048..%d), oracle = restated '
+                         'ParallelInterpreted (src/render.rs:35-99), %.1f s' % (rows, W, 2048 + rows, ct)}
+
+    if rank == 0:
+        line = {
+            'metric': 'Mpixels/s on chess.maray @4096x4096',
+            'value': value, 'unit': 'Mpixels/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'data/chess.maray rescaled x4 to 4096 px wide (SURVEY.md §8(d) config 3); '
+                                   'each rank evaluates its own 4096x4096-pixel row tile of a 4096 x %d image'
+                                   % h_total,
+                       'backend': backend_name, 'kernel': ctx.kernel_name, 'pixels_per_step': px_per_step,
+                       'tape_ops_per_pixel': tape.info['n_pix_ops'], 'parallelism': 'row tiles, no collective',
+                       'bit_exact_vs_golden': parity},
+            'roofline': {'bound': 'valu_f64', 'achieved': achieved, 'peak': PEAK_F64_TOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_F64_TOPS, 'traffic': None,
+                         'kernel_ms': k_ms, 'alg_ops_per_pixel': ALG_OPS_PER_PIXEL,
+                         'hbm': {'achieved': hbm_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                 'frac': hbm_gbs / PEAK_HBM_GBS, 'bytes_per_pixel': 3}},
+            'cpu_baseline': cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

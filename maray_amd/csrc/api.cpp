@@ -1,0 +1,338 @@
+// api.cpp — extern "C" boundary of libmaray_hip.so (product code).
+// Every function converts maray::Error into a code + thread-local message and
+// never lets an exception cross the ABI.
+#include <pthread.h>
+
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "backend.hpp"
+#include "expr.hpp"
+#include "lower.hpp"
+#include "maray_hip.h"
+
+using namespace maray;
+
+struct maray_scene { Scene s; };
+struct maray_tape { Tape t; };
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &m) { g_err = m; return code; }
+
+// Deeply nested expressions recurse deeply; run the recursive passes on a
+// thread with a large (lazily committed) stack.
+struct BigStack {
+    std::function<void()> fn;
+    Error err{0, ""};
+    bool threw = false, bad_alloc = false;
+};
+void *big_stack_main(void *p)
+{
+    BigStack *b = (BigStack *)p;
+    try { b->fn(); }
+    catch (const Error &e) { b->err = e; b->threw = true; }
+    catch (const std::bad_alloc &) { b->bad_alloc = true; }
+    catch (const std::exception &e) { b->err = Error{MARAY_E_INTERNAL, e.what()}; b->threw = true; }
+    return nullptr;
+}
+void run_big_stack(std::function<void()> fn)
+{
+    BigStack b;
+    b.fn = std::move(fn);
+    pthread_attr_t at;
+    pthread_attr_init(&at);
+    pthread_attr_setstacksize(&at, (size_t)1 << 30);
+    pthread_t th;
+    if (pthread_create(&th, &at, big_stack_main, &b) != 0) {
+        pthread_attr_destroy(&at);
+        big_stack_main(&b);
+    } else {
+        pthread_attr_destroy(&at);
+        pthread_join(th, nullptr);
+    }
+    if (b.bad_alloc) throw Error{MARAY_E_INTERNAL, "out of memory"};
+    if (b.threw) throw b.err;
+}
+
+template <typename F>
+int guard(F f)
+{
+    try { f(); g_err.clear(); return MARAY_OK; }
+    catch (const Error &e) { return fail(e.code, e.msg); }
+    catch (const std::bad_alloc &) { return fail(MARAY_E_INTERNAL, "out of memory"); }
+    catch (const std::exception &e) { return fail(MARAY_E_INTERNAL, e.what()); }
+    catch (...) { return fail(MARAY_E_INTERNAL, "unknown error"); }
+}
+
+#define REQUIRE(c, what) do { if (!(c)) throw Error{MARAY_E_ARG, what}; } while (0)
+
+}   // namespace
+
+namespace maray {
+
+void set_last_error(const std::string &m) { g_err = m; }
+
+void validate_program(const maray_program &p)
+{
+    if (p.version != MARAY_TAPE_VERSION) throw Error{MARAY_E_ARG, "tape version mismatch"};
+    if ((p.n_consts && !p.consts) || (p.n_row_ops && !p.row_ops) || (p.n_pix_ops && !p.pix_ops))
+        throw Error{MARAY_E_ARG, "null section pointer"};
+    if (p.n_row_slots > MARAY_MAX_SLOTS || p.n_pix_slots > MARAY_MAX_SLOTS) throw Error{MARAY_E_LIMIT, "too many slots"};
+    auto check = [&](const uint64_t *ops, uint32_t n, uint32_t n_slots, bool pixel) {
+        std::vector<uint8_t> written(n_slots, 0);
+        bool have_acc = false;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint64_t ins = ops[i];
+            const uint32_t op = MARAY_INS_OP(ins), aux = MARAY_INS_AUX(ins), dst = MARAY_INS_DST(ins);
+            if (op >= MARAY_OP_COUNT) throw Error{MARAY_E_ARG, "invalid opcode at op " + std::to_string(i)};
+            if (op == MARAY_OP_NOP) continue;
+            const int arity = (op == MARAY_OP_TEXDIM) ? 0 : (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) ? 2 : 1;
+            const uint32_t refs[2] = {MARAY_INS_A(ins), MARAY_INS_B(ins)};
+            for (int k = 0; k < arity; k++) {
+                const uint32_t kind = MARAY_REF_KIND(refs[k]), idx = MARAY_REF_INDEX(refs[k]);
+                bool ok = true;
+                switch (kind) {
+                case MARAY_K_SLOT: ok = idx < n_slots && written[idx]; break;
+                case MARAY_K_CONST: ok = idx < p.n_consts; break;
+                case MARAY_K_YVAL: ok = pixel && idx < p.n_yvals; break;
+                default: ok = idx <= MARAY_SPEC_ACC && (idx != MARAY_SPEC_ACC || have_acc) && (idx != MARAY_SPEC_X || pixel);
+                }
+                if (!ok) throw Error{MARAY_E_ARG, "operand out of range or read before write at op " + std::to_string(i)};
+            }
+            if (op == MARAY_OP_OUT) {
+                if (aux >= (pixel ? 3u : p.n_yvals)) throw Error{MARAY_E_ARG, "output index out of range at op " + std::to_string(i)};
+                continue;
+            }
+            if ((op == MARAY_OP_APP || op == MARAY_OP_TEXDIM) && aux >= p.n_app)
+                throw Error{MARAY_E_ARG, "App id above n_app at op " + std::to_string(i)};
+            if (dst != MARAY_DST_NONE) {
+                if (dst >= n_slots) throw Error{MARAY_E_ARG, "dst slot out of range at op " + std::to_string(i)};
+                written[dst] = 1;
+            }
+            have_acc = true;
+        }
+    };
+    check(p.row_ops, p.n_row_ops, p.n_row_slots, false);
+    check(p.pix_ops, p.n_pix_ops, p.n_pix_slots, true);
+}
+
+}   // namespace maray
+
+extern "C" {
+
+const char *maray_last_error(void) { return g_err.c_str(); }
+const char *maray_version(void) { return "maray_amd 0.1 (gfx950; tape v1; mirrors maray 0.3.8)"; }
+
+// ---- scenes ------------------------------------------------------------------
+int maray_scene_from_bytes(const uint8_t *buf, size_t len, maray_scene **out)
+{
+    return guard([&] {
+        REQUIRE(buf && out, "null argument");
+        *out = nullptr;
+        maray_scene *s = new maray_scene();
+        try { run_big_stack([&] { scene_decode(buf, len, s->s); }); }
+        catch (...) { delete s; throw; }
+        *out = s;
+    });
+}
+
+int maray_scene_open(const char *path, maray_scene **out)
+{
+    return guard([&] {
+        REQUIRE(path && out, "null argument");
+        *out = nullptr;
+        FILE *f = fopen(path, "rb");
+        if (!f) throw Error{MARAY_E_IO, std::string("cannot open ") + path};
+        std::vector<uint8_t> b;
+        uint8_t tmp[65536];
+        size_t n;
+        while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) b.insert(b.end(), tmp, tmp + n);
+        fclose(f);
+        maray_scene *s = new maray_scene();
+        try { run_big_stack([&] { scene_decode(b.data(), b.size(), s->s); }); }
+        catch (...) { delete s; throw; }
+        *out = s;
+    });
+}
+
+void maray_scene_free(maray_scene *s) { delete s; }
+
+int maray_scene_size(const maray_scene *s, uint32_t *w, uint32_t *h)
+{
+    return guard([&] { REQUIRE(s && w && h, "null argument"); *w = s->s.w; *h = s->s.h; });
+}
+
+int maray_scene_set_size(maray_scene *s, uint32_t w, uint32_t h)
+{
+    return guard([&] { REQUIRE(s, "null argument"); s->s.w = w; s->s.h = h; });
+}
+
+int maray_scene_is_legacy(const maray_scene *s, int *legacy)
+{
+    return guard([&] { REQUIRE(s && legacy, "null argument"); *legacy = s->s.legacy ? 1 : 0; });
+}
+
+int maray_scene_node_count(const maray_scene *s, int c, uint64_t *n)
+{
+    return guard([&] {
+        REQUIRE(s && n && c >= 0 && c < 3, "bad argument");
+        run_big_stack([&] { *n = scene_node_count(s->s, c); });
+    });
+}
+
+int maray_scene_encode(const maray_scene *s, uint8_t *out, size_t cap, size_t *len_out)
+{
+    return guard([&] {
+        REQUIRE(s && len_out, "null argument");
+        std::vector<uint8_t> b;
+        run_big_stack([&] { scene_encode(s->s, b); });
+        *len_out = b.size();
+        if (out && cap >= b.size()) memcpy(out, b.data(), b.size());
+    });
+}
+
+int maray_scene_save(const maray_scene *s, const char *path)
+{
+    return guard([&] {
+        REQUIRE(s && path, "null argument");
+        std::vector<uint8_t> b;
+        run_big_stack([&] { scene_encode(s->s, b); });
+        FILE *f = fopen(path, "wb");
+        if (!f) throw Error{MARAY_E_IO, std::string("cannot create ") + path};
+        size_t n = fwrite(b.data(), 1, b.size(), f);
+        fclose(f);
+        if (n != b.size()) throw Error{MARAY_E_IO, "short write"};
+    });
+}
+
+int maray_scene_fix_color(maray_scene *s)
+{
+    return guard([&] { REQUIRE(s, "null argument"); run_big_stack([&] { scene_fix_color(s->s); }); });
+}
+
+int maray_scene_rescale(maray_scene *s, uint32_t sx, uint32_t sy)
+{
+    return guard([&] { REQUIRE(s, "null argument"); scene_rescale(s->s, sx, sy); });
+}
+
+// ---- lowering -----------------------------------------------------------------
+int maray_lower(const maray_scene *s, const maray_lower_opts *opts, maray_tape **out)
+{
+    return guard([&] {
+        REQUIRE(s && out, "null argument");
+        *out = nullptr;
+        maray_lower_opts o;
+        memset(&o, 0, sizeof o);
+        o.hoist_rows = 1;
+        if (opts) o = *opts;
+        maray_tape *t = new maray_tape();
+        try {
+            run_big_stack([&] { lower_scene(s->s, o, t->t); });
+            validate_program(t->t.program());
+        } catch (...) { delete t; throw; }
+        *out = t;
+    });
+}
+
+void maray_tape_free(maray_tape *t) { delete t; }
+
+int maray_tape_program(const maray_tape *t, maray_program *out)
+{
+    return guard([&] { REQUIRE(t && out, "null argument"); *out = t->t.program(); });
+}
+
+int maray_tape_get_info(const maray_tape *t, maray_tape_info *out)
+{
+    return guard([&] { REQUIRE(t && out, "null argument"); *out = t->t.info; });
+}
+
+// ---- device ---------------------------------------------------------------------
+int maray_hip_device_count(int *n)
+{
+    return guard([&] { REQUIRE(n, "null argument"); *n = hip_device_count(); });
+}
+
+int maray_hip_ctx_create(int device, const maray_program *prog, const maray_texture *tex, uint32_t n_tex,
+                         const maray_ctx_opts *opts, maray_ctx **out)
+{
+    return guard([&] {
+        REQUIRE(prog && out, "null argument");
+        REQUIRE(n_tex == 0 || tex, "null texture table");
+        *out = nullptr;
+        validate_program(*prog);
+        if (prog->n_app > 5u * n_tex)   // reference: rt.functions[id] panics (src/lib.rs:665)
+            throw Error{MARAY_E_APP_RANGE, "scene calls App id " + std::to_string(prog->n_app - 1) + " but only " +
+                        std::to_string(5u * n_tex) + " texture functions exist"};
+        for (uint32_t i = 0; i < n_tex; i++) REQUIRE(tex[i].rgb || (uint64_t)tex[i].w * tex[i].h == 0, "null texture raster");
+        const uint32_t backend = opts ? opts->backend : MARAY_BACKEND_TAPE;
+        Backend *b = nullptr;
+        switch (backend) {
+        case MARAY_BACKEND_TAPE: b = make_tape_backend(device, *prog, tex, n_tex, true); break;
+        case MARAY_BACKEND_TAPE_SMEM: b = make_tape_backend(device, *prog, tex, n_tex, false); break;
+        case MARAY_BACKEND_JIT: b = make_jit_backend(device, *prog, tex, n_tex); break;
+        default: throw Error{MARAY_E_ARG, "unknown backend"};
+        }
+        maray_ctx *c = new maray_ctx();
+        c->backend = b;
+        c->n_tex = n_tex;
+        *out = c;
+    });
+}
+
+void maray_hip_ctx_free(maray_ctx *c)
+{
+    if (!c) return;
+    delete c->backend;
+    delete c;
+}
+
+static void check_rows(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1)
+{
+    (void)w;
+    if (y0 > y1 || y1 > h) throw Error{MARAY_E_ARG, "row range out of bounds"};
+}
+
+int maray_hip_render_rows(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint8_t *rgb8, double *rgb64)
+{
+    return guard([&] {
+        REQUIRE(c && c->backend, "null context");
+        check_rows(w, h, y0, y1);
+        if (y0 == y1 || w == 0 || (!rgb8 && !rgb64)) return;
+        c->backend->render_host(w, h, y0, y1, rgb8, rgb64);
+    });
+}
+
+int maray_hip_render_rows_device(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
+                                 void *d_rgb8, void *d_rgb64, void *stream)
+{
+    return guard([&] {
+        REQUIRE(c && c->backend, "null context");
+        check_rows(w, h, y0, y1);
+        if (y0 == y1 || w == 0) return;
+        c->backend->render_device(w, h, y0, y1, d_rgb8, d_rgb64, stream);
+    });
+}
+
+int maray_hip_time_rows(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
+                        void *d_rgb8, void *d_rgb64, int reps, float *ms_avg)
+{
+    return guard([&] {
+        REQUIRE(c && c->backend && ms_avg, "null argument");
+        check_rows(w, h, y0, y1);
+        REQUIRE(y1 > y0 && w > 0 && reps > 0, "empty launch");
+        *ms_avg = c->backend->time_rows(w, h, y0, y1, d_rgb8, d_rgb64, reps);
+    });
+}
+
+const char *maray_hip_kernel_name(const maray_ctx *c) { return (c && c->backend) ? c->backend->kernel_name() : ""; }
+
+void maray_free(void *p) { free(p); }
+
+}   // extern "C"

@@ -1,0 +1,65 @@
+// device_math.h — scalar f64 semantics of the tape ops on gfx950 (product code).
+//
+// One definition of every op of `Expr::eval2` (src/lib.rs:623-670) shared by the
+// tape interpreter kernels and the hiprtc-specialised kernels.  Compiled with
+// -ffp-contract=off: a*b+c is never fused unless written as fma().
+#pragma once
+
+#include "maray_libm.h"
+
+#define MARAY_DEV __device__ __forceinline__
+
+// Neg Abs Recip Sqrt: IEEE-754 exact (:640-643).  1.0/a and sqrt lower to the
+// correctly rounded f64 expansions (no fast-math).
+MARAY_DEV double mr_neg(double a) { return -a; }
+MARAY_DEV double mr_abs(double a) { return __builtin_fabs(a); }
+MARAY_DEV double mr_recip(double a) { return 1.0 / a; }
+MARAY_DEV double mr_sqrt(double a) { return __builtin_sqrt(a); }
+// Step (:644-647): NaN -> 0, -0.0 -> 1.
+MARAY_DEV double mr_step(double a) { return a >= 0.0 ? 1.0 : 0.0; }
+// f64::max / f64::min (:655-658): NaN-ignoring = v_max_f64 / v_min_f64
+// (quiet NaN operand -> the other operand; -0 < +0).
+MARAY_DEV double mr_max(double a, double b) { return __builtin_fmax(a, b); }
+MARAY_DEV double mr_min(double a, double b) { return __builtin_fmin(a, b); }
+// Sin Exp Ln (:648-650): the platform libm of the reference host = glibc 2.35
+// x86_64 FMA variants, reproduced bit for bit (maray_libm.h).
+MARAY_DEV double mr_sin(double a) { return maray_libm_sin(a); }
+MARAY_DEV double mr_exp(double a) { return maray_libm_exp(a); }
+MARAY_DEV double mr_ln(double a) { return maray_libm_log(a); }
+
+// Rust `f64 as u8` (src/render.rs:92-94): saturating, NaN -> 0, truncation.
+MARAY_DEV unsigned mr_cast_u8(double v)
+{
+    if (!(v > 0.0)) return 0u;
+    if (v >= 255.0) return 255u;
+    return (unsigned)v;
+}
+// Rust `f64 as u32` (src/textures.rs:32-33): saturating, NaN -> 0.
+MARAY_DEV unsigned mr_cast_u32(double v)
+{
+    if (!(v > 0.0)) return 0u;
+    if (v >= 4294967295.0) return 4294967295u;
+    return (unsigned)v;
+}
+
+struct MarayTex {
+    const unsigned char *rgb;
+    unsigned w, h;
+};
+
+// textures::fun_color_channel (src/textures.rs:27-36): id = image*5 + channel.
+MARAY_DEV double mr_app(const MarayTex *tex, unsigned id, double x, double y)
+{
+    const MarayTex t = tex[id / 5u];
+    const unsigned sel = id % 5u;
+    if (x < 0.0 || y < 0.0) return 0.0;              // :30
+    const unsigned xi = mr_cast_u32(x), yi = mr_cast_u32(y);   // :32-33
+    if (xi >= t.w || yi >= t.h) return 0.0;          // :34
+    return (double)t.rgb[((size_t)yi * t.w + xi) * 3u + sel];  // :35
+}
+// fun_image_width / fun_image_height (src/textures.rs:40-50).
+MARAY_DEV double mr_texdim(const MarayTex *tex, unsigned id)
+{
+    const MarayTex t = tex[id / 5u];
+    return (id % 5u) == 3u ? (double)t.w : (double)t.h;
+}

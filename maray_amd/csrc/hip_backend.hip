@@ -1,0 +1,374 @@
+// hip_backend.hip — gfx950 evaluators behind the tape-level C ABI (product code).
+//
+// Replaces the per-pixel loop of par_gen_to_image / wasm_par_gen_to_image
+// (src/render.rs:85-97, :168-183): one work-item per pixel, the tape walked
+// once per wavefront with wave-uniform dispatch (the op word lives in SGPRs,
+// the switch is a scalar branch, every lane executes the same VALU op).
+//
+// Data layout in HBM (uploaded once at ctx creation):
+//   tape      n_ops  x u64      (ROW section, PIXEL section)
+//   consts    n_consts x f64
+//   textures  RGB8 rasters + a MarayTex descriptor table
+//   yvals     rows x n_yvals f64   (written by the ROW kernel, read as scalars)
+//   spill     (n_slots - n_lds_slots) x grid_threads f64, only if the value
+//             slots do not fit in LDS
+// Outputs: rgb8 (rows*w*3 bytes) and/or rgb64 (rows*w*3 doubles), interleaved.
+//
+// LDS layout of the pixel kernel (dynamic):
+//   [ tape (TAPE_LDS only) | consts (TAPE_LDS only) | slots: n_lds_slots x 256 f64 ]
+// Slot s of thread t is at slots[s*256 + t]: ds_read_b64/ds_write_b64 hit 64
+// consecutive 8-byte words per wave, conflict-free.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "backend.hpp"
+#include "device_math.h"
+#include "maray_hip.h"
+
+namespace maray {
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+struct KArgs {
+    const uint64_t *tape;      // section to run
+    const double *consts;
+    const double *yvals;       // PIXEL: rows x n_yvals (row-major); ROW: unused
+    double *yout;              // ROW: rows x n_yvals
+    double *spill;             // [slot - n_lds_slots][grid_threads]
+    const MarayTex *tex;
+    unsigned char *rgb8;
+    double *rgb64;
+    uint32_t n_ops, n_consts, n_yvals, n_slots, n_lds_slots;
+    uint32_t w, y0, rows;      // image width, first row, row count of this launch
+    uint32_t tiles_per_row, n_tiles;
+};
+
+typedef const __attribute__((address_space(4))) uint64_t *k_u64_ptr;   // constant address space: scalar loads
+typedef const __attribute__((address_space(4))) double *k_f64_ptr;
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// One pass over a tape section for the calling work-item.
+//   ROW = false: item is a pixel, OUT k -> out[k] (k = 0,1,2)
+//   ROW = true : item is an image row, OUT k -> yout[k]
+template <bool TAPE_LDS, bool ROW>
+__device__ __forceinline__ void run_tape(const KArgs &A, const uint64_t *tape_lds, const double *consts_lds,
+                                         double *slots, double *spill_base, uint32_t spill_stride,
+                                         const double *yrow, double X, double Y, double *yout,
+                                         double &o0, double &o1, double &o2)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_lds = A.n_lds_slots;
+    double acc = 0.0;
+    k_u64_ptr tape_k = (k_u64_ptr)A.tape;
+    k_f64_ptr consts_k = (k_f64_ptr)A.consts;
+    k_f64_ptr yrow_k = (k_f64_ptr)yrow;
+
+    auto fetch = [&](uint32_t ref) -> double {
+        const uint32_t kind = ref >> 14, idx = ref & 0x3FFFu;   // wave-uniform
+        if (kind == MARAY_K_SLOT) return idx < n_lds ? slots[idx * BLOCK + tid] : spill_base[(size_t)(idx - n_lds) * spill_stride];
+        if (kind == MARAY_K_CONST) return TAPE_LDS ? consts_lds[idx] : consts_k[idx];
+        if (kind == MARAY_K_YVAL) return yrow_k[idx];
+        return idx == MARAY_SPEC_X ? X : (idx == MARAY_SPEC_Y ? Y : acc);
+    };
+
+    for (uint32_t pc = 0; pc < A.n_ops; ++pc) {
+        uint32_t lo, hi;
+        if (TAPE_LDS) {
+            const uint64_t ins = tape_lds[pc];           // same LDS address in every lane: broadcast read
+            lo = uni((uint32_t)ins); hi = uni((uint32_t)(ins >> 32));
+        } else {
+            const uint64_t ins = tape_k[pc];             // s_load through the scalar cache
+            lo = uni((uint32_t)ins); hi = uni((uint32_t)(ins >> 32));
+        }
+        const uint32_t op = lo & 0x7Fu, aux = (lo >> 7) & 0x1FFFu, dst = lo >> 20;
+        const uint32_t ra = hi & 0xFFFFu, rb = hi >> 16;
+        double r;
+        switch (op) {
+        case MARAY_OP_MOV: r = fetch(ra); break;
+        case MARAY_OP_NEG: r = mr_neg(fetch(ra)); break;
+        case MARAY_OP_ABS: r = mr_abs(fetch(ra)); break;
+        case MARAY_OP_RECIP: r = mr_recip(fetch(ra)); break;
+        case MARAY_OP_SQRT: r = mr_sqrt(fetch(ra)); break;
+        case MARAY_OP_STEP: r = mr_step(fetch(ra)); break;
+        case MARAY_OP_SIN: r = mr_sin(fetch(ra)); break;
+        case MARAY_OP_EXP: r = mr_exp(fetch(ra)); break;
+        case MARAY_OP_LN: r = mr_ln(fetch(ra)); break;
+        case MARAY_OP_ADD: { const double a = fetch(ra), b = fetch(rb); r = a + b; break; }
+        case MARAY_OP_MUL: { const double a = fetch(ra), b = fetch(rb); r = a * b; break; }
+        case MARAY_OP_MAX: { const double a = fetch(ra), b = fetch(rb); r = mr_max(a, b); break; }
+        case MARAY_OP_MIN: { const double a = fetch(ra), b = fetch(rb); r = mr_min(a, b); break; }
+        case MARAY_OP_APP: { const double a = fetch(ra), b = fetch(rb); r = mr_app(A.tex, aux, a, b); break; }
+        case MARAY_OP_TEXDIM: r = mr_texdim(A.tex, aux); break;
+        case MARAY_OP_OUT: {
+            const double v = fetch(ra);
+            if (ROW) yout[aux] = v;
+            else if (aux == 0) o0 = v;
+            else if (aux == 1) o1 = v;
+            else o2 = v;
+            continue;                                     // OUT leaves ACC and slots untouched
+        }
+        default: continue;                                // NOP
+        }
+        acc = r;
+        if (dst != MARAY_DST_NONE) {
+            if (dst < n_lds) slots[dst * BLOCK + tid] = r;
+            else spill_base[(size_t)(dst - n_lds) * spill_stride] = r;
+        }
+    }
+}
+
+// PIXEL kernel.  Block = 256 consecutive pixels of one row ("tile"); blocks
+// stride over tiles so the LDS staging of the tape is paid once per block.
+template <bool TAPE_LDS>
+__global__ void __launch_bounds__(BLOCK) maray_tape_pixels(const KArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint64_t *tape_lds = nullptr;
+    const double *consts_lds = nullptr;
+    double *slots;
+    if (TAPE_LDS) {
+        uint64_t *tl = (uint64_t *)smem;
+        double *cl = (double *)(smem + (size_t)A.n_ops * 8);
+        for (uint32_t i = threadIdx.x; i < A.n_ops; i += BLOCK) tl[i] = A.tape[i];
+        for (uint32_t i = threadIdx.x; i < A.n_consts; i += BLOCK) cl[i] = A.consts[i];
+        tape_lds = tl; consts_lds = cl;
+        slots = (double *)(smem + ((size_t)A.n_ops + A.n_consts) * 8);
+        __syncthreads();
+    } else {
+        slots = (double *)smem;
+    }
+    const uint32_t spill_stride = gridDim.x * BLOCK;
+    double *spill_base = A.spill ? A.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
+
+    for (uint32_t tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+        const uint32_t r = tile / A.tiles_per_row;                 // row within this launch (uniform)
+        const uint32_t x = (tile - r * A.tiles_per_row) * BLOCK + threadIdx.x;
+        const uint32_t y = A.y0 + r;
+        const double *yrow = A.yvals + (size_t)r * A.n_yvals;
+        double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+        run_tape<TAPE_LDS, false>(A, tape_lds, consts_lds, slots, spill_base, spill_stride, yrow,
+                                  (double)x, (double)y, nullptr, o0, o1, o2);      // p = [x as f64, y as f64]
+        if (x < A.w) {
+            const size_t p = ((size_t)r * A.w + x) * 3;
+            if (A.rgb64) { A.rgb64[p] = o0; A.rgb64[p + 1] = o1; A.rgb64[p + 2] = o2; }
+            if (A.rgb8) {
+                A.rgb8[p] = (unsigned char)mr_cast_u8(o0);
+                A.rgb8[p + 1] = (unsigned char)mr_cast_u8(o1);
+                A.rgb8[p + 2] = (unsigned char)mr_cast_u8(o2);
+            }
+        }
+    }
+}
+
+// ROW kernel: one work-item per image row evaluates the ROW section and writes
+// the row's y values.  Tiny (rows x n_row_ops); slots live in LDS or spill.
+__global__ void __launch_bounds__(BLOCK) maray_tape_rows(const KArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *slots = (double *)smem;
+    const uint32_t spill_stride = gridDim.x * BLOCK;
+    double *spill_base = A.spill ? A.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
+    const uint32_t r = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t rr = r < A.rows ? r : A.rows - 1;               // keep the wave uniform; surplus lanes recompute the last row
+    double o0, o1, o2;
+    run_tape<false, true>(A, nullptr, nullptr, slots, spill_base, spill_stride, nullptr,
+                          0.0, (double)(A.y0 + rr), A.yout + (size_t)rr * A.n_yvals, o0, o1, o2);
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            throw Error{MARAY_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)};           \
+    } while (0)
+
+struct TapeBackend final : Backend {
+    int device = 0;
+    bool tape_lds = true;
+    hipDeviceProp_t prop{};
+    maray_program P{};
+    uint64_t *d_row_ops = nullptr, *d_pix_ops = nullptr;
+    double *d_consts = nullptr;
+    MarayTex *d_tex = nullptr;
+    std::vector<unsigned char *> d_tex_rgb;
+    double *d_yvals = nullptr; size_t yvals_cap = 0;
+    double *d_spill = nullptr; size_t spill_cap = 0;
+    unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;
+    double *d_rgb64 = nullptr; size_t rgb64_cap = 0;
+    hipStream_t own_stream = nullptr;
+    // launch geometry of the pixel kernel
+    uint32_t n_lds_slots = 0, lds_bytes = 0, blocks_per_cu = 1;
+    uint32_t row_lds_slots = 0, row_lds_bytes = 0;
+    std::string kname;
+
+    ~TapeBackend() override {
+        hipSetDevice(device);
+        hipFree(d_row_ops); hipFree(d_pix_ops); hipFree(d_consts); hipFree(d_tex);
+        for (auto p : d_tex_rgb) hipFree(p);
+        hipFree(d_yvals); hipFree(d_spill); hipFree(d_rgb8); hipFree(d_rgb64);
+        if (own_stream) hipStreamDestroy(own_stream);
+    }
+
+    void init(int dev, const maray_program &prog, const maray_texture *tex, uint32_t n_tex, bool lds_variant) {
+        device = dev;
+        HIP_TRY(hipSetDevice(dev));
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+            throw Error{MARAY_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only"};
+        P = prog;
+        P.consts = nullptr; P.row_ops = nullptr; P.pix_ops = nullptr;   // host pointers are borrowed for this call only
+        HIP_TRY(hipStreamCreate(&own_stream));
+        auto up = [&](const void *src, size_t bytes, void **dst) {
+            HIP_TRY(hipMalloc(dst, bytes ? bytes : 8));
+            if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        };
+        up(prog.row_ops, (size_t)prog.n_row_ops * 8, (void **)&d_row_ops);
+        up(prog.pix_ops, (size_t)prog.n_pix_ops * 8, (void **)&d_pix_ops);
+        up(prog.consts, (size_t)prog.n_consts * 8, (void **)&d_consts);
+        std::vector<MarayTex> descs(n_tex ? n_tex : 1);
+        for (uint32_t i = 0; i < n_tex; i++) {
+            unsigned char *d = nullptr;
+            up(tex[i].rgb, (size_t)tex[i].w * tex[i].h * 3, (void **)&d);
+            d_tex_rgb.push_back(d);
+            descs[i] = MarayTex{d, tex[i].w, tex[i].h};
+        }
+        up(descs.data(), descs.size() * sizeof(MarayTex), (void **)&d_tex);
+
+        // LDS budget: 160 KiB per workgroup on gfx950
+        const size_t lds_cap = 163840;
+        size_t base = lds_variant ? ((size_t)prog.n_pix_ops + prog.n_consts) * 8 : 0;
+        base = (base + 15) & ~(size_t)15;
+        tape_lds = lds_variant;
+        if (lds_variant && base + (size_t)BLOCK * 8 > lds_cap)
+            throw Error{MARAY_E_LIMIT, "tape does not fit in LDS (" + std::to_string(base) + " bytes); use MARAY_BACKEND_TAPE_SMEM or MARAY_BACKEND_JIT"};
+        const size_t slot_bytes = (size_t)BLOCK * 8;
+        n_lds_slots = (uint32_t)std::min<size_t>(prog.n_pix_slots, (lds_cap - base) / slot_bytes);
+        lds_bytes = (uint32_t)(base + (size_t)n_lds_slots * slot_bytes);
+        blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, lds_cap / std::max<uint32_t>(lds_bytes, 1)));
+        row_lds_slots = (uint32_t)std::min<size_t>(prog.n_row_slots, 65536 / slot_bytes);
+        row_lds_bytes = (uint32_t)(row_lds_slots * slot_bytes);
+        if (lds_variant) {
+            HIP_TRY(hipFuncSetAttribute((const void *)maray_tape_pixels<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+            kname = "maray_tape_pixels<true>";
+        } else {
+            HIP_TRY(hipFuncSetAttribute((const void *)maray_tape_pixels<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+            kname = "maray_tape_pixels<false>";
+        }
+    }
+
+    template <typename T>
+    void ensure(T *&p, size_t &cap, size_t n) {
+        if (n <= cap) return;
+        if (p) HIP_TRY(hipFree(p));
+        p = nullptr; cap = 0;
+        HIP_TRY(hipMalloc((void **)&p, n * sizeof(T)));
+        cap = n;
+    }
+
+    void launch(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, unsigned char *d8, double *d64, hipStream_t st, bool rows_pass) {
+        (void)h;
+        const uint32_t rows = y1 - y0;
+        if (!rows || !w) return;
+        ensure(d_yvals, yvals_cap, (size_t)rows * std::max<uint32_t>(P.n_yvals, 1));
+        if (rows_pass && P.n_row_ops) {
+            KArgs R{};
+            R.tape = d_row_ops; R.consts = d_consts; R.yout = d_yvals; R.tex = d_tex;
+            R.n_ops = P.n_row_ops; R.n_consts = P.n_consts; R.n_yvals = P.n_yvals;
+            R.n_slots = P.n_row_slots; R.n_lds_slots = row_lds_slots;
+            R.w = w; R.y0 = y0; R.rows = rows;
+            const uint32_t grid = (rows + BLOCK - 1) / BLOCK;
+            if (P.n_row_slots > row_lds_slots) {
+                ensure(d_spill, spill_cap, std::max(spill_cap, (size_t)(P.n_row_slots - row_lds_slots) * grid * BLOCK));
+                R.spill = d_spill;
+            }
+            hipLaunchKernelGGL(maray_tape_rows, dim3(grid), dim3(BLOCK), row_lds_bytes, st, R);
+            HIP_TRY(hipGetLastError());
+        }
+        KArgs A{};
+        A.tape = d_pix_ops; A.consts = d_consts; A.yvals = d_yvals; A.tex = d_tex;
+        A.rgb8 = d8; A.rgb64 = d64;
+        A.n_ops = P.n_pix_ops; A.n_consts = P.n_consts; A.n_yvals = P.n_yvals;
+        A.n_slots = P.n_pix_slots; A.n_lds_slots = n_lds_slots;
+        A.w = w; A.y0 = y0; A.rows = rows;
+        A.tiles_per_row = (w + BLOCK - 1) / BLOCK;
+        const uint64_t tiles = (uint64_t)A.tiles_per_row * rows;
+        if (tiles > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
+        A.n_tiles = (uint32_t)tiles;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, (uint64_t)prop.multiProcessorCount * blocks_per_cu);
+        if (P.n_pix_slots > n_lds_slots) {
+            ensure(d_spill, spill_cap, std::max(spill_cap, (size_t)(P.n_pix_slots - n_lds_slots) * grid * BLOCK));
+            A.spill = d_spill;
+        }
+        if (tape_lds) hipLaunchKernelGGL(maray_tape_pixels<true>, dim3(grid), dim3(BLOCK), lds_bytes, st, A);
+        else hipLaunchKernelGGL(maray_tape_pixels<false>, dim3(grid), dim3(BLOCK), lds_bytes, st, A);
+        HIP_TRY(hipGetLastError());
+    }
+
+    void render_device(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, void *d8, void *d64, void *stream) override {
+        HIP_TRY(hipSetDevice(device));
+        launch(w, h, y0, y1, (unsigned char *)d8, (double *)d64, (hipStream_t)stream, true);
+    }
+
+    void render_host(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint8_t *rgb8, double *rgb64) override {
+        HIP_TRY(hipSetDevice(device));
+        const size_t n = (size_t)(y1 - y0) * w * 3;
+        if (rgb8) ensure(d_rgb8, rgb8_cap, n);
+        if (rgb64) ensure(d_rgb64, rgb64_cap, n);
+        launch(w, h, y0, y1, rgb8 ? d_rgb8 : nullptr, rgb64 ? d_rgb64 : nullptr, own_stream, true);
+        if (rgb8) HIP_TRY(hipMemcpyAsync(rgb8, d_rgb8, n, hipMemcpyDeviceToHost, own_stream));
+        if (rgb64) HIP_TRY(hipMemcpyAsync(rgb64, d_rgb64, n * 8, hipMemcpyDeviceToHost, own_stream));
+        HIP_TRY(hipStreamSynchronize(own_stream));
+    }
+
+    float time_rows(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, void *d8, void *d64, int reps) override {
+        HIP_TRY(hipSetDevice(device));
+        const size_t n = (size_t)(y1 - y0) * w * 3;
+        unsigned char *p8 = (unsigned char *)d8;
+        double *p64 = (double *)d64;
+        if (!p8 && !p64) { ensure(d_rgb8, rgb8_cap, n); p8 = d_rgb8; }
+        launch(w, h, y0, y1, p8, p64, own_stream, true);   // warm-up + y values
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, own_stream));
+        for (int i = 0; i < reps; i++) launch(w, h, y0, y1, p8, p64, own_stream, false);   // pixel kernel only
+        HIP_TRY(hipEventRecord(e1, own_stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        return ms / (float)(reps > 0 ? reps : 1);
+    }
+
+    const char *kernel_name() const override { return kname.c_str(); }
+};
+
+}   // namespace
+
+int hip_device_count()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+Backend *make_tape_backend(int device, const maray_program &prog, const maray_texture *tex, uint32_t n_tex, bool lds_variant)
+{
+    if (hip_device_count() <= 0) throw Error{MARAY_E_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)"};
+    auto *b = new TapeBackend();
+    try {
+        b->init(device, prog, tex, n_tex, lds_variant);
+    } catch (...) {
+        delete b;
+        throw;
+    }
+    return b;
+}
+
+}   // namespace maray

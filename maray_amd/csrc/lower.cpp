@@ -1,0 +1,460 @@
+// lower.cpp — Expr -> tape lowering (product code).
+//
+// One-time replacement for what the reference does per pixel in
+// `Expr::eval2` + `Cache` (src/lib.rs:623-670, src/cache.rs:6-42):
+//
+//  1. fix_color (src/var_fixer.rs:74-82), as every renderer does first
+//     (src/render.rs:14,51,117).
+//  2. Symbolic evaluation of R, G, B into one hash-consed DAG: Let replaces
+//     the context (src/lib.rs:659-662), Var resolves to the first matching
+//     definition of the current context (src/cache.rs:32-33) or NaN (:40),
+//     Arc/Decor are transparent (:633,:663).  The reference's Cache is keyed by
+//     id alone; it is value-transparent iff every id resolves to one DAG node
+//     at all of its use sites — checked here, MARAY_E_ALIASED otherwise.
+//  3. Constant folding with IEEE-exact ops only (neg abs recip sqrt step add
+//     mul max min); sin/exp/ln are never evaluated on the host.
+//  4. Dependence classes: Y-only ops go to the ROW section (once per row),
+//     everything that depends on X to the PIXEL section.
+//  5. Sethi-Ullman ordered DFS schedule (keeps few values live), linear-scan
+//     slot allocation, ACC forwarding of results consumed by the next op.
+#include "lower.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <unordered_map>
+#include <unordered_set>
+
+#include "maray_hip.h"
+
+namespace maray {
+
+namespace {
+
+enum : uint8_t { D_CONST = 100, D_X = 101, D_Y = 102 };   // leaf kinds; ops use MARAY_OP_*
+enum : uint8_t { DEP_X = 1, DEP_Y = 2 };
+
+struct DNode {
+    uint8_t op;
+    uint8_t dep;
+    uint32_t aux;
+    int32_t a, b;
+    double cval;
+};
+
+inline uint64_t bits_of(double v) { uint64_t u; memcpy(&u, &v, 8); return u; }
+
+// f64::max / f64::min (src/lib.rs:655-658): NaN-ignoring; for +0 vs -0 the
+// IEEE 754-2019 maximumNumber/minimumNumber choice, which is what v_max_f64 /
+// v_min_f64 compute on gfx950.
+inline double rs_max(double a, double b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) return std::signbit(a) ? b : a;
+    return a > b ? a : b;
+}
+inline double rs_min(double a, double b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) return std::signbit(a) ? a : b;
+    return a < b ? a : b;
+}
+
+struct KeyHash {
+    size_t operator()(const std::array<uint64_t, 3> &k) const {
+        uint64_t h = k[0] * 0x9e3779b97f4a7c15ULL;
+        h ^= (k[1] + 0x7f4a7c15ULL + (h << 6) + (h >> 2));
+        h *= 0xff51afd7ed558ccdULL;
+        h ^= (k[2] + (h << 6) + (h >> 2));
+        return (size_t)(h ^ (h >> 29));
+    }
+};
+
+struct Dag {
+    std::vector<DNode> n;
+    std::unordered_map<std::array<uint64_t, 3>, int32_t, KeyHash> map;
+    uint32_t folded = 0;
+    bool commute = true;
+
+    int32_t intern(const DNode &d) {
+        std::array<uint64_t, 3> k = {(uint64_t)d.op | ((uint64_t)d.aux << 8), ((uint64_t)(uint32_t)d.a << 32) | (uint32_t)d.b,
+                                     d.op == D_CONST ? bits_of(d.cval) : 0};
+        auto it = map.find(k);
+        if (it != map.end()) return it->second;
+        n.push_back(d);
+        int32_t id = (int32_t)n.size() - 1;
+        map.emplace(k, id);
+        return id;
+    }
+    int32_t konst(double v) {
+        if (v != v) v = NAN;   // one canonical NaN
+        return intern(DNode{D_CONST, 0, 0, -1, -1, v});
+    }
+    int32_t leaf(uint8_t kind) { return intern(DNode{kind, kind == D_X ? DEP_X : DEP_Y, 0, -1, -1, 0.0}); }
+
+    int32_t unary(uint8_t op, int32_t a) {
+        if (n[a].op == D_CONST) {
+            double v = n[a].cval;
+            switch (op) {
+            case MARAY_OP_NEG: folded++; return konst(-v);
+            case MARAY_OP_ABS: folded++; return konst(std::fabs(v));
+            case MARAY_OP_RECIP: folded++; return konst(1.0 / v);
+            case MARAY_OP_SQRT: folded++; return konst(std::sqrt(v));
+            case MARAY_OP_STEP: folded++; return konst(v >= 0.0 ? 1.0 : 0.0);
+            default: break;   // sin / exp / ln are evaluated on the device only
+            }
+        }
+        return intern(DNode{op, n[a].dep, 0, a, -1, 0.0});
+    }
+    int32_t binary(uint8_t op, int32_t a, int32_t b) {
+        if (n[a].op == D_CONST && n[b].op == D_CONST) {
+            double x = n[a].cval, y = n[b].cval;
+            folded++;
+            switch (op) {
+            case MARAY_OP_ADD: return konst(x + y);
+            case MARAY_OP_MUL: return konst(x * y);
+            case MARAY_OP_MAX: return konst(rs_max(x, y));
+            default: return konst(rs_min(x, y));
+            }
+        }
+        if (commute && a > b) std::swap(a, b);   // + * max min are commutative in value: canonical operand order
+        return intern(DNode{op, (uint8_t)(n[a].dep | n[b].dep), 0, a, b, 0.0});
+    }
+    int32_t app(uint32_t id, int32_t a, int32_t b) {
+        if (id % 5u >= 3u) return intern(DNode{MARAY_OP_TEXDIM, 0, id, -1, -1, 0.0});   // width/height ignore a, b
+        return intern(DNode{MARAY_OP_APP, (uint8_t)(n[a].dep | n[b].dep), id, a, b, 0.0});
+    }
+};
+
+// ---- symbolic evaluation -------------------------------------------------------
+struct SymEval {
+    const Scene &s;
+    Dag &g;
+    std::unordered_map<uint64_t, int32_t> memo;         // (expr, ctx) -> dag node
+    std::unordered_map<uint64_t, int32_t> var_memo;     // (ctx, def index) -> dag node
+    std::unordered_set<uint64_t> in_progress;
+    std::unordered_map<uint64_t, int32_t> id_node;      // Var id -> dag node at its use sites (Cache transparency)
+    int depth = 0;
+
+    SymEval(const Scene &s_, Dag &g_) : s(s_), g(g_) {}
+
+    int32_t var(uint64_t id, int32_t ctx) {
+        int32_t r = -1;
+        if (ctx >= 0) {
+            const Ctx &c = s.ctxs[ctx];
+            for (size_t i = 0; i < c.ids.size(); i++) {
+                if (c.ids[i] != id) continue;                       // first match wins (src/cache.rs:32-33)
+                uint64_t k = ((uint64_t)(uint32_t)ctx << 32) | (uint32_t)i;
+                auto it = var_memo.find(k);
+                if (it != var_memo.end()) { r = it->second; break; }
+                if (!in_progress.insert(k).second)
+                    throw Error{MARAY_E_CYCLE, "Let variable " + std::to_string(id) + " is defined in terms of itself"};
+                r = eval(c.defs[i], ctx);                            // definitions see their own Let's ctx (src/cache.rs:34)
+                in_progress.erase(k);
+                var_memo.emplace(k, r);
+                break;
+            }
+        }
+        if (r < 0) r = g.konst(NAN);                                 // unknown variable (src/cache.rs:40)
+        auto ins = id_node.emplace(id, r);
+        if (!ins.second && ins.first->second != r)
+            throw Error{MARAY_E_ALIASED, "variable id " + std::to_string(id) +
+                        " resolves to different values in different scopes; the reference's id-keyed Cache makes the result order dependent"};
+        return r;
+    }
+
+    int32_t eval(int32_t e, int32_t ctx) {
+        uint64_t key = ((uint64_t)(uint32_t)e << 32) | (uint32_t)(ctx + 1);
+        auto it = memo.find(key);
+        if (it != memo.end()) return it->second;
+        if (++depth > 2000000) throw Error{MARAY_E_LIMIT, "expression too deep"};
+        const Node &n = s.nodes[e];
+        int32_t r;
+        switch (n.tag) {
+        case T_ARC: case T_DECOR: r = eval(n.a, ctx); break;         // :633, :663
+        case T_X: r = g.leaf(D_X); break;
+        case T_Y: r = g.leaf(D_Y); break;
+        case T_TAU: r = g.konst(6.283185307179586); break;           // :636
+        case T_E: r = g.konst(2.718281828459045); break;             // :637
+        case T_VAR: r = var(n.u, ctx); break;                        // :638
+        case T_NAT: r = g.konst((double)n.u); break;                 // :639 `n as f64`
+        case T_LET: r = eval(n.a, n.ctx); break;                     // :659-662 ctx replaced
+        case T_APP: {
+            int32_t a = eval(n.a, ctx), b = eval(n.b, ctx);
+            r = g.app(n.app, a, b);
+            break;
+        }
+        default:
+            if (is_binary(n.tag)) {
+                int32_t a = eval(n.a, ctx), b = eval(n.b, ctx);
+                static const uint8_t ops[] = {MARAY_OP_ADD, MARAY_OP_MUL, MARAY_OP_MAX, MARAY_OP_MIN};
+                r = g.binary(ops[n.tag - T_ADD], a, b);
+            } else {
+                static const uint8_t ops[] = {MARAY_OP_NEG, MARAY_OP_ABS, MARAY_OP_RECIP, MARAY_OP_SQRT,
+                                              MARAY_OP_STEP, MARAY_OP_SIN, MARAY_OP_EXP, MARAY_OP_LN};
+                r = g.unary(ops[n.tag - T_NEG], eval(n.a, ctx));
+            }
+        }
+        depth--;
+        memo.emplace(key, r);
+        return r;
+    }
+};
+
+// ---- section scheduling + encoding --------------------------------------------------
+struct Section {
+    std::vector<int32_t> order;                 // computing nodes in schedule order
+    std::vector<std::pair<int32_t, uint32_t>> outs;   // (node, output index)
+    std::vector<uint64_t> ops;
+    uint32_t n_slots = 0;
+    uint32_t acc_operands = 0;
+};
+
+struct Lowerer {
+    const Dag &g;
+    std::vector<uint8_t> in_section;            // node belongs to the section being built
+    std::vector<int32_t> need;                  // Sethi-Ullman label
+    std::vector<uint8_t> visited;
+    std::unordered_map<uint64_t, uint32_t> const_index;
+    std::vector<double> consts;
+    std::vector<int32_t> yval_of;               // node -> y value index or -1
+
+    explicit Lowerer(const Dag &g_) : g(g_), yval_of(g_.n.size(), -1) {}
+
+    uint32_t const_ref(double v) {
+        uint64_t b = bits_of(v);
+        auto it = const_index.find(b);
+        if (it != const_index.end()) return it->second;
+        uint32_t i = (uint32_t)consts.size();
+        if (i > MARAY_MAX_INDEX) throw Error{MARAY_E_LIMIT, "more than 16384 distinct constants"};
+        consts.push_back(v);
+        const_index.emplace(b, i);
+        return i;
+    }
+
+    int32_t su(int32_t i) {
+        if (need[i] >= 0) return need[i];
+        const DNode &d = g.n[i];
+        int32_t na = (d.a >= 0 && in_section[d.a]) ? su(d.a) : 0;
+        int32_t nb = (d.b >= 0 && in_section[d.b] && d.b != d.a) ? su(d.b) : 0;
+        int32_t r;
+        if (!na && !nb) r = 1;
+        else if (na == nb) r = na + 1;
+        else r = std::max(na, nb);
+        need[i] = r;
+        return r;
+    }
+
+    void visit(int32_t i, Section &sec) {
+        if (visited[i] || !in_section[i]) return;
+        visited[i] = 1;
+        const DNode &d = g.n[i];
+        int32_t c0 = d.a, c1 = d.b;
+        bool h0 = c0 >= 0 && in_section[c0], h1 = c1 >= 0 && in_section[c1];
+        if (h0 && h1 && su(c1) > su(c0)) std::swap(c0, c1);   // heavier sub-tree first
+        if (c0 >= 0) visit(c0, sec);
+        if (c1 >= 0) visit(c1, sec);
+        sec.order.push_back(i);
+    }
+
+    void build(Section &sec, bool pixel) {
+        size_t N = g.n.size();
+        need.assign(N, -1);
+        visited.assign(N, 0);
+        for (auto &o : sec.outs) if (in_section[o.first]) visit(o.first, sec);
+
+        // Item list: each computing node, followed immediately by the OUT ops that read it.
+        struct Item { int32_t node; int32_t out; };   // out >= 0: OUT op of output `out` reading `node`
+        std::vector<Item> items;
+        std::unordered_map<int32_t, std::vector<uint32_t>> outs_of;
+        for (auto &o : sec.outs) outs_of[o.first].push_back(o.second);
+        std::vector<int32_t> item_pos(N, -1);          // position of the item that LAST leaves node in ACC
+        for (int32_t nd : sec.order) {
+            items.push_back({nd, -1});
+            item_pos[nd] = (int32_t)items.size() - 1;
+            // OUT does not modify ACC, so consecutive OUTs of one node all read ACC
+        }
+        // insert OUTs: rebuild with OUTs right after their node
+        {
+            std::vector<Item> with;
+            with.reserve(items.size() + sec.outs.size());
+            for (const Item &it : items) {
+                with.push_back(it);
+                auto f = outs_of.find(it.node);
+                if (f != outs_of.end()) for (uint32_t k : f->second) with.push_back({it.node, (int32_t)k});
+            }
+            for (auto &o : sec.outs) if (!in_section[o.first]) with.push_back({o.first, (int32_t)o.second});   // const / leaf / yval roots
+            items.swap(with);
+        }
+        // positions and last uses
+        std::vector<int32_t> last_use(N, -1), first_far_use(N, 0);
+        std::fill(item_pos.begin(), item_pos.end(), -1);
+        std::vector<int32_t> acc_pos(N, -1);   // item index after which ACC holds node (until the next computing item)
+        for (size_t j = 0; j < items.size(); j++) if (items[j].out < 0) item_pos[items[j].node] = (int32_t)j;
+        // ACC validity: ACC holds the result of the latest computing item; OUT items do not disturb it.
+        std::vector<int32_t> acc_holder(items.size(), -1);
+        {
+            int32_t cur = -1;
+            for (size_t j = 0; j < items.size(); j++) {
+                acc_holder[j] = cur;                   // node in ACC when item j executes
+                if (items[j].out < 0) cur = items[j].node;
+            }
+        }
+        auto note_use = [&](int32_t c, size_t j) {
+            if (c < 0 || !in_section[c]) return;
+            last_use[c] = (int32_t)j;
+            if (acc_holder[j] != c) first_far_use[c] = 1;   // some use cannot be served by ACC -> needs a slot
+        };
+        for (size_t j = 0; j < items.size(); j++) {
+            if (items[j].out >= 0) note_use(items[j].node, j);
+            else { note_use(g.n[items[j].node].a, j); note_use(g.n[items[j].node].b, j); }
+        }
+
+        // linear scan
+        std::vector<int32_t> slot(N, -1);
+        std::vector<uint32_t> free_slots;              // min-heap of free slot numbers
+        uint32_t next_slot = 0;
+        auto alloc = [&]() -> uint32_t {
+            if (!free_slots.empty()) {
+                std::pop_heap(free_slots.begin(), free_slots.end(), std::greater<uint32_t>());
+                uint32_t s = free_slots.back(); free_slots.pop_back(); return s;
+            }
+            if (next_slot >= MARAY_MAX_SLOTS) throw Error{MARAY_E_LIMIT, "more than 4095 live values"};
+            return next_slot++;
+        };
+        auto release = [&](int32_t c, size_t j) {
+            if (c >= 0 && in_section[c] && slot[c] >= 0 && last_use[c] == (int32_t)j) {
+                free_slots.push_back((uint32_t)slot[c]);
+                std::push_heap(free_slots.begin(), free_slots.end(), std::greater<uint32_t>());
+                slot[c] = -2;   // released
+            }
+        };
+        auto opref = [&](int32_t c, size_t j) -> uint32_t {
+            const DNode &d = g.n[c];
+            if (d.op == D_CONST) return MARAY_REF(MARAY_K_CONST, const_ref(d.cval));
+            if (d.op == D_X) return MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_X);
+            if (d.op == D_Y) return MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_Y);
+            if (in_section[c]) {
+                if (acc_holder[j] == c) { sec.acc_operands++; return MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_ACC); }
+                if (slot[c] < 0) throw Error{MARAY_E_INTERNAL, "operand without a slot"};
+                return MARAY_REF(MARAY_K_SLOT, (uint32_t)slot[c]);
+            }
+            if (pixel && yval_of[c] >= 0) {
+                if ((uint32_t)yval_of[c] > MARAY_MAX_INDEX) throw Error{MARAY_E_LIMIT, "more than 16384 row values"};
+                return MARAY_REF(MARAY_K_YVAL, (uint32_t)yval_of[c]);
+            }
+            throw Error{MARAY_E_INTERNAL, "operand outside its section"};
+        };
+        for (size_t j = 0; j < items.size(); j++) {
+            const Item &it = items[j];
+            if (it.out >= 0) {
+                uint32_t a = opref(it.node, j);
+                release(it.node, j);
+                sec.ops.push_back(MARAY_INS(MARAY_OP_OUT, (uint32_t)it.out, MARAY_DST_NONE, a, 0));
+                continue;
+            }
+            const DNode &d = g.n[it.node];
+            uint32_t a = d.a >= 0 ? opref(d.a, j) : 0;
+            uint32_t b = d.b >= 0 ? opref(d.b, j) : 0;
+            release(d.a, j);
+            if (d.b != d.a) release(d.b, j);
+            uint32_t dst = MARAY_DST_NONE;
+            if (first_far_use[it.node]) { dst = alloc(); slot[it.node] = (int32_t)dst; }
+            if (d.aux > 0x1FFFu) throw Error{MARAY_E_LIMIT, "App id above 8191"};
+            sec.ops.push_back(MARAY_INS(d.op, d.aux, dst, a, b));
+        }
+        sec.n_slots = next_slot;
+    }
+};
+
+}   // namespace
+
+void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
+{
+    Scene s = scene_in;
+    scene_fix_color(s);
+
+    Dag g;
+    g.commute = opts.plain_cse == 0;
+    SymEval ev(s, g);
+    int32_t roots[3];
+    for (int c = 0; c < 3; c++) roots[c] = ev.eval(s.color[c], -1);   // outer Context::new() is empty (src/render.rs:53)
+
+    const size_t N = g.n.size();
+    // reachability from the roots
+    std::vector<uint8_t> reach(N, 0);
+    {
+        std::vector<int32_t> st(roots, roots + 3);
+        while (!st.empty()) {
+            int32_t i = st.back(); st.pop_back();
+            if (reach[i]) continue;
+            reach[i] = 1;
+            if (g.n[i].a >= 0) st.push_back(g.n[i].a);
+            if (g.n[i].b >= 0) st.push_back(g.n[i].b);
+        }
+    }
+    auto is_op = [&](int32_t i) { return g.n[i].op < D_CONST; };
+
+    maray_tape_info &info = t.info;
+    memset(&info, 0, sizeof info);
+    info.folded_ops = g.folded;
+    uint32_t max_app = 0;
+    for (size_t i = 0; i < N; i++) {
+        if (!reach[i]) continue;
+        info.dag_nodes++;
+        if (!is_op((int32_t)i)) continue;
+        info.alg_ops++;
+        switch (g.n[i].dep) {
+        case 0: info.alg_ops_uniform++; break;
+        case DEP_X: info.alg_ops_x++; break;
+        case DEP_Y: info.alg_ops_y++; break;
+        default: info.alg_ops_xy++;
+        }
+        if (g.n[i].op == MARAY_OP_APP || g.n[i].op == MARAY_OP_TEXDIM) max_app = std::max(max_app, g.n[i].aux + 1);
+    }
+    info.n_app = max_app;
+
+    Lowerer L(g);
+    const bool hoist = opts.hoist_rows != 0;
+    // ROW section: reachable ops that do not depend on X.
+    Section row, pix;
+    std::vector<uint8_t> is_row(N, 0);
+    if (hoist) for (size_t i = 0; i < N; i++) if (reach[i] && is_op((int32_t)i) && !(g.n[i].dep & DEP_X)) is_row[i] = 1;
+    // y values = ROW nodes consumed by PIXEL ops or by a channel output
+    {
+        std::vector<uint8_t> frontier(N, 0);
+        for (size_t i = 0; i < N; i++) {
+            if (!reach[i] || !is_op((int32_t)i) || is_row[i]) continue;
+            for (int32_t c : {g.n[i].a, g.n[i].b}) if (c >= 0 && is_row[c]) frontier[c] = 1;
+        }
+        for (int c = 0; c < 3; c++) if (is_row[roots[c]]) frontier[roots[c]] = 1;
+        uint32_t k = 0;
+        for (size_t i = 0; i < N; i++) if (frontier[i]) { L.yval_of[i] = (int32_t)k; row.outs.push_back({(int32_t)i, k}); k++; }
+        info.n_yvals = k;
+        if (k > MARAY_MAX_INDEX + 1) throw Error{MARAY_E_LIMIT, "more than 16384 row values"};
+    }
+    L.in_section = is_row;
+    L.build(row, false);
+
+    std::vector<uint8_t> is_pix(N, 0);
+    for (size_t i = 0; i < N; i++) if (reach[i] && is_op((int32_t)i) && !is_row[i]) is_pix[i] = 1;
+    for (int c = 0; c < 3; c++) pix.outs.push_back({roots[c], (uint32_t)c});
+    L.in_section = is_pix;
+    L.build(pix, true);
+
+    t.consts = std::move(L.consts);
+    if (t.consts.empty()) t.consts.push_back(0.0);
+    t.row_ops = std::move(row.ops);
+    t.pix_ops = std::move(pix.ops);
+    info.n_consts = (uint32_t)t.consts.size();
+    info.n_row_ops = (uint32_t)t.row_ops.size();
+    info.n_row_slots = row.n_slots;
+    info.n_pix_ops = (uint32_t)t.pix_ops.size();
+    info.n_pix_slots = pix.n_slots;
+    info.acc_operands = pix.acc_operands;
+    for (uint64_t ins : t.pix_ops) info.op_histogram[MARAY_INS_OP(ins)]++;
+}
+
+}   // namespace maray

@@ -1,0 +1,172 @@
+// png.cpp — PNG writer/reader used by gen() and the CLI (product code).
+//
+//   maray_png_write <- `img.save(file)`                 src/lib.rs:1207,1212
+//   maray_png_read  <- `image::open(file).to_rgb8()`    examples/maray.rs:60-65
+//
+// The reference delegates to the `image`/`png` crates; PNG container bytes are
+// an encoder choice, so parity is defined on the decoded RGB8 raster
+// (SURVEY.md §8(c)).  Writer: 8-bit RGB, filter 0, zlib level 6.  Reader:
+// non-interlaced gray / RGB / palette / gray+alpha / RGBA at 8 or 16 bits
+// (and 1/2/4-bit gray or palette), converted like `to_rgb8` (alpha dropped,
+// 16-bit -> high byte... see below).
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "backend.hpp"
+#include "maray_hip.h"
+
+using namespace maray;
+
+namespace {
+
+void put_be32(std::vector<uint8_t> &v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
+
+void chunk(std::vector<uint8_t> &out, const char *type, const uint8_t *data, size_t n)
+{
+    put_be32(out, (uint32_t)n);
+    size_t start = out.size();
+    out.insert(out.end(), type, type + 4);
+    if (n) out.insert(out.end(), data, data + n);
+    uint32_t crc = (uint32_t)crc32(0L, out.data() + start, (uInt)(n + 4));
+    put_be32(out, crc);
+}
+
+uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+int paeth(int a, int b, int c)
+{
+    int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    if (pa <= pb && pa <= pc) return a;
+    return pb <= pc ? b : c;
+}
+
+}   // namespace
+
+extern "C" int maray_png_write(const char *path, const uint8_t *rgb8, uint32_t w, uint32_t h)
+{
+    if (!path || (!rgb8 && (uint64_t)w * h)) { set_last_error("null argument"); return MARAY_E_ARG; }
+    std::vector<uint8_t> raw;
+    raw.reserve(((size_t)w * 3 + 1) * h);
+    for (uint32_t y = 0; y < h; y++) {
+        raw.push_back(0);   // filter type None
+        raw.insert(raw.end(), rgb8 + (size_t)y * w * 3, rgb8 + (size_t)(y + 1) * w * 3);
+    }
+    uLongf zn = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zn);
+    if (compress2(z.data(), &zn, raw.data(), (uLong)raw.size(), 6) != Z_OK) { set_last_error("zlib compress failed"); return MARAY_E_INTERNAL; }
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, w); put_be32(ihdr, h);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);   // 8-bit, truecolour
+    chunk(out, "IHDR", ihdr.data(), ihdr.size());
+    chunk(out, "IDAT", z.data(), zn);
+    chunk(out, "IEND", nullptr, 0);
+    FILE *f = fopen(path, "wb");
+    if (!f) { set_last_error(std::string("cannot create ") + path); return MARAY_E_IO; }
+    size_t n = fwrite(out.data(), 1, out.size(), f);
+    fclose(f);
+    if (n != out.size()) { set_last_error("short write"); return MARAY_E_IO; }
+    return MARAY_OK;
+}
+
+extern "C" int maray_png_read(const char *path, uint8_t **rgb8_out, uint32_t *w_out, uint32_t *h_out)
+{
+    if (!path || !rgb8_out || !w_out || !h_out) { set_last_error("null argument"); return MARAY_E_ARG; }
+    *rgb8_out = nullptr;
+    FILE *f = fopen(path, "rb");
+    if (!f) { set_last_error(std::string("cannot open ") + path); return MARAY_E_IO; }
+    std::vector<uint8_t> b;
+    uint8_t tmp[65536];
+    size_t n;
+    while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) b.insert(b.end(), tmp, tmp + n);
+    fclose(f);
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    if (b.size() < 8 || memcmp(b.data(), sig, 8)) { set_last_error("not a PNG file"); return MARAY_E_DECODE; }
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8_t> idat, plte;
+    size_t pos = 8;
+    bool seen_ihdr = false;
+    while (pos + 12 <= b.size()) {
+        uint32_t len = be32(&b[pos]);
+        if (pos + 12 + (size_t)len > b.size()) { set_last_error("truncated PNG chunk"); return MARAY_E_DECODE; }
+        const uint8_t *type = &b[pos + 4], *data = &b[pos + 8];
+        if (!memcmp(type, "IHDR", 4) && len >= 13) {
+            w = be32(data); h = be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12]; seen_ihdr = true;
+        } else if (!memcmp(type, "PLTE", 4)) plte.assign(data, data + len);
+        else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
+        else if (!memcmp(type, "IEND", 4)) break;
+        pos += 12 + (size_t)len;
+    }
+    if (!seen_ihdr || !w || !h) { set_last_error("PNG without IHDR"); return MARAY_E_DECODE; }
+    if (interlace) { set_last_error("interlaced PNG is not supported"); return MARAY_E_DECODE; }
+    int channels;
+    switch (ctype) {
+    case 0: channels = 1; break;
+    case 2: channels = 3; break;
+    case 3: channels = 1; break;
+    case 4: channels = 2; break;
+    case 6: channels = 4; break;
+    default: set_last_error("bad PNG colour type"); return MARAY_E_DECODE;
+    }
+    if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) {
+        set_last_error("bad PNG bit depth"); return MARAY_E_DECODE;
+    }
+    const size_t bpp_bits = (size_t)channels * depth;
+    const size_t stride = ((size_t)w * bpp_bits + 7) / 8;
+    const size_t bpp = (bpp_bits + 7) / 8;
+    std::vector<uint8_t> raw((stride + 1) * h);
+    uLongf rn = (uLongf)raw.size();
+    if (uncompress(raw.data(), &rn, idat.data(), (uLong)idat.size()) != Z_OK || rn != raw.size()) {
+        set_last_error("PNG inflate failed"); return MARAY_E_DECODE;
+    }
+    std::vector<uint8_t> prev(stride, 0), cur(stride);
+    uint8_t *out = (uint8_t *)malloc((size_t)w * h * 3);
+    if (!out) { set_last_error("out of memory"); return MARAY_E_INTERNAL; }
+    for (uint32_t y = 0; y < h; y++) {
+        const uint8_t *line = &raw[(stride + 1) * y];
+        const int ft = line[0];
+        for (size_t i = 0; i < stride; i++) {
+            int a = i >= bpp ? cur[i - bpp] : 0, bb = prev[i], c = i >= bpp ? prev[i - bpp] : 0, x = line[1 + i];
+            switch (ft) {
+            case 0: break;
+            case 1: x += a; break;
+            case 2: x += bb; break;
+            case 3: x += (a + bb) / 2; break;
+            case 4: x += paeth(a, bb, c); break;
+            default: free(out); set_last_error("bad PNG filter"); return MARAY_E_DECODE;
+            }
+            cur[i] = (uint8_t)x;
+        }
+        uint8_t *o = out + (size_t)y * w * 3;
+        for (uint32_t x = 0; x < w; x++) {
+            auto sample = [&](int ch) -> unsigned {   // 8-bit value of channel ch of pixel x
+                if (depth == 8) return cur[(size_t)x * channels + ch];
+                if (depth == 16) {   // image crate: 16 -> 8 bit by rounding division (v * 255 + 32767) / 65535
+                    unsigned v = ((unsigned)cur[((size_t)x * channels + ch) * 2] << 8) | cur[((size_t)x * channels + ch) * 2 + 1];
+                    return (v * 255u + 32767u) / 65535u;
+                }
+                size_t bit = (size_t)x * depth;
+                unsigned v = (cur[bit / 8] >> (8 - depth - (bit % 8))) & ((1u << depth) - 1u);
+                return ctype == 3 ? v : v * 255u / ((1u << depth) - 1u);
+            };
+            if (ctype == 3) {
+                unsigned idx = depth == 8 ? cur[x] : sample(0);
+                for (int k = 0; k < 3; k++) o[x * 3 + k] = (idx * 3 + k < plte.size()) ? plte[idx * 3 + k] : 0;
+            } else if (ctype == 0 || ctype == 4) {
+                unsigned g = sample(0);
+                o[x * 3] = o[x * 3 + 1] = o[x * 3 + 2] = (uint8_t)g;
+            } else {
+                for (int k = 0; k < 3; k++) o[x * 3 + k] = (uint8_t)sample(k);
+            }
+        }
+        prev.swap(cur);
+    }
+    *rgb8_out = out; *w_out = w; *h_out = h;
+    return MARAY_OK;
+}

@@ -1,0 +1,64 @@
+"""Synthetic scenes of SURVEY.md §8(d) (configs 2, 3b, 5) built with the test builders."""
+import numpy as np
+
+from marayb import (abs_, add, app, channel, clamp_u8, div, exp, image_width, ln, max_, mul, nat, neg, sin, sqrt, sub,
+                    x, y)
+
+
+def radial_gradient():
+    """Config 2: c = Sqrt(Add(Mul(X,X), Mul(Y,Y))), color = [c,c,c]."""
+    c = sqrt(add(mul(x(), x()), mul(y(), y())))
+    return [c, c, c]
+
+
+def all_ops(w, h):
+    """Config 3b: every computing variant of Expr, different phase per channel:
+    clamp_u8(255 * (1/2 + 1/2 * sin(ln(1 + sqrt(u^2+v^2)) * 8 + k) * exp(-abs(u*v)))), u = x/W - 1/2, v = y/H - 1/2."""
+    u = sub(div(x(), nat(w)), div(nat(1), nat(2)))
+    v = sub(div(y(), nat(h)), div(nat(1), nat(2)))
+    r = sqrt(add(mul(u, u), mul(v, v)))
+    out = []
+    for k in (0, 1, 2):
+        s = sin(add(mul(ln(add(nat(1), r)), nat(8)), nat(k)))
+        e = exp(neg(abs_(mul(u, v))))
+        val = mul(nat(255), add(div(nat(1), nat(2)), mul(mul(div(nat(1), nat(2)), s), e)))
+        out.append(clamp_u8(val))
+    return out
+
+
+def splitmix64(seed, n):
+    """n bytes of splitmix64 output (little-endian words), seed 0x6d61726179 = "maray"."""
+    out = bytearray()
+    s = seed & 0xFFFFFFFFFFFFFFFF
+    while len(out) < n:
+        s = (s + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        z ^= z >> 31
+        out += z.to_bytes(8, 'little')
+    return bytes(out[:n])
+
+
+def textures(scale=1):
+    """T0 (1024/scale)^2, T1 (2048/scale) x (512/scale), RGB8 from splitmix64."""
+    w0 = h0 = 1024 // scale
+    w1, h1 = 2048 // scale, 512 // scale
+    raw = splitmix64(0x6d61726179, (w0 * h0 + w1 * h1) * 3)
+    t0 = np.frombuffer(raw[:w0 * h0 * 3], np.uint8).reshape(h0, w0, 3).copy()
+    t1 = np.frombuffer(raw[w0 * h0 * 3:], np.uint8).reshape(h1, w1, 3).copy()
+    return [t0, t1]
+
+
+def textured(w):
+    """Config 5 (pattern of examples/test6.rs:5-9): per channel
+    Max(App(channel(0,c), X/4, Y/4), App(channel(1,c), (W - X)/2, Y/8)), plus one image_width(1) use."""
+    out = []
+    for c in (0, 1, 2):
+        a = app(channel(0, c), mul(x(), div(nat(1), nat(4))), mul(y(), div(nat(1), nat(4))))
+        b = app(channel(1, c), mul(add(nat(w), neg(x())), div(nat(1), nat(2))), mul(y(), div(nat(1), nat(8))))
+        e = max_(a, b)
+        if c == 2:   # selectors 3/4: scale blue by width(T1)/width(T1) == 1 through an App
+            e = mul(e, div(app(image_width(1), x(), y()), app(image_width(1), nat(0), nat(0))))
+        out.append(e)
+    return out

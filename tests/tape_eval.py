@@ -1,0 +1,122 @@
+"""Reference evaluator of the tape format (include/maray_tape.h) in numpy.
+
+Test infrastructure for the host logic: it lets the CPU suite check that the
+lowering (Expr -> tape) preserves the oracle's values without a GPU.  It is not
+part of the product and is never used on a render path.  sin/exp/ln go through
+Python's math module (= the platform libm the oracle calls).
+"""
+import math
+
+import numpy as np
+
+OP = dict(NOP=0, MOV=1, NEG=2, ABS=3, RECIP=4, SQRT=5, STEP=6, SIN=7, EXP=8, LN=9, ADD=10, MUL=11, MAX=12, MIN=13,
+          APP=14, TEXDIM=15, OUT=16)
+K_SLOT, K_CONST, K_YVAL, K_SPEC = 0, 1, 2, 3
+DST_NONE = 0xFFF
+
+_vsin = np.vectorize(math.sin, otypes=[np.float64])
+_vexp = np.vectorize(lambda v: math.exp(v) if v < 709.782712893384 else (math.inf if v == v else v), otypes=[np.float64])
+
+
+def _vlog(a):
+    out = np.empty_like(a)
+    for i, v in np.ndenumerate(a):
+        if v != v: out[i] = v
+        elif v > 0: out[i] = math.log(v)
+        elif v == 0: out[i] = -math.inf
+        else: out[i] = math.nan
+    return out
+
+
+def _sin(a):
+    with np.errstate(all='ignore'):
+        fin = np.isfinite(a)
+        out = np.full_like(a, np.nan)
+        out[fin] = _vsin(a[fin])
+    return out
+
+
+def decode(ins):
+    ins = int(ins)
+    return (ins & 0x7F, (ins >> 7) & 0x1FFF, (ins >> 20) & 0xFFF, (ins >> 32) & 0xFFFF, (ins >> 48) & 0xFFFF)
+
+
+def _cast_u32(v):
+    v = np.where(v > 0, v, 0.0)          # NaN / negatives -> 0
+    return np.minimum(v, 4294967295.0).astype(np.uint64)
+
+
+def run_section(ops, consts, n_slots, X, Y, yvals, textures, n_out):
+    """Evaluate one section for a vector of items.  X, Y: float64 arrays (same
+    shape); yvals: array [..., n_yvals] broadcastable per item or None."""
+    shape = np.shape(Y)
+    slots = [None] * max(n_slots, 1)
+    outs = [None] * n_out
+    acc = None
+
+    def fetch(ref):
+        kind, idx = ref >> 14, ref & 0x3FFF
+        if kind == K_SLOT: return slots[idx]
+        if kind == K_CONST: return np.full(shape, consts[idx])
+        if kind == K_YVAL: return yvals[..., idx]
+        return X if idx == 0 else (Y if idx == 1 else acc)
+
+    with np.errstate(all='ignore'):
+        for ins in ops:
+            op, aux, dst, ra, rb = decode(ins)
+            if op == OP['NOP']: continue
+            if op == OP['OUT']:
+                outs[aux] = fetch(ra); continue
+            if op == OP['MOV']: r = fetch(ra)
+            elif op == OP['NEG']: r = -fetch(ra)
+            elif op == OP['ABS']: r = np.abs(fetch(ra))
+            elif op == OP['RECIP']: r = 1.0 / fetch(ra)
+            elif op == OP['SQRT']: r = np.sqrt(fetch(ra))
+            elif op == OP['STEP']: r = np.where(fetch(ra) >= 0.0, 1.0, 0.0)
+            elif op == OP['SIN']: r = _sin(fetch(ra))
+            elif op == OP['EXP']: r = _vexp(fetch(ra))
+            elif op == OP['LN']: r = _vlog(fetch(ra))
+            elif op == OP['ADD']: r = fetch(ra) + fetch(rb)
+            elif op == OP['MUL']: r = fetch(ra) * fetch(rb)
+            elif op == OP['MAX']: r = np.fmax(fetch(ra), fetch(rb))
+            elif op == OP['MIN']: r = np.fmin(fetch(ra), fetch(rb))
+            elif op == OP['TEXDIM']:
+                t = textures[aux // 5]
+                r = np.full(shape, float(t.shape[1] if aux % 5 == 3 else t.shape[0]))
+            elif op == OP['APP']:
+                t = textures[aux // 5]
+                a, b = fetch(ra), fetch(rb)
+                h, w = t.shape[0], t.shape[1]
+                xi, yi = _cast_u32(a), _cast_u32(b)
+                inb = ~((a < 0) | (b < 0)) & (xi < w) & (yi < h)
+                r = np.zeros(shape)
+                r[inb] = t[yi[inb].astype(np.int64), xi[inb].astype(np.int64), aux % 5].astype(np.float64)
+            else:
+                raise ValueError('bad opcode %d' % op)
+            acc = r
+            if dst != DST_NONE:
+                slots[dst] = r
+    return outs
+
+
+def render_rows(tape, w, y0, y1, textures=None):
+    """Evaluate a maray_amd.Tape over rows [y0,y1) x [0,w) -> (rows, w, 3) float64."""
+    consts, row_ops, pix_ops = tape.arrays()
+    info = tape.info
+    rows = y1 - y0
+    ys = np.arange(y0, y1, dtype=np.float64)
+    yv = None
+    if info['n_yvals']:
+        outs = run_section(row_ops, consts, info['n_row_slots'], None, ys, None, textures, info['n_yvals'])
+        yv = np.stack(outs, axis=-1)                       # (rows, n_yvals)
+        yv = np.broadcast_to(yv[:, None, :], (rows, w, info['n_yvals']))
+    X = np.broadcast_to(np.arange(w, dtype=np.float64)[None, :], (rows, w)).copy()
+    Y = np.broadcast_to(ys[:, None], (rows, w)).copy()
+    o = run_section(pix_ops, consts, info['n_pix_slots'], X, Y, yv, textures, 3)
+    return np.stack(o, axis=-1)
+
+
+def cast_u8(v):
+    """Rust `as u8`."""
+    v = np.where(v > 0, v, 0.0)
+    return np.minimum(v, 255.0).astype(np.uint8)

@@ -1,0 +1,148 @@
+"""Host logic of the product (reader, fix_color, Expr -> tape lowering) checked
+against the oracle on the CPU.  The tape is evaluated by tests/tape_eval.py
+(numpy), never by the product."""
+import math
+
+import numpy as np
+import pytest
+
+import maray_amd as M
+import scenes
+import tape_eval
+from marayb import (add, arc, decode, decor, encode, encode_expr, let_, mul, nat, sin, step, sub, subst_xy_deep,
+                    var_id, x, y, recip, div, max_, min_)
+from oracle_ffi import Scene as OScene
+
+
+def same_f64(a, b):
+    """Bit-exact comparison of f64 planes; all NaNs compare equal (x86 and gfx950
+    generate different default NaN signs; NaN never reaches a non-NaN output)."""
+    a = np.asarray(a); b = np.asarray(b)
+    nan = np.isnan(a) & np.isnan(b)
+    return np.array_equal(np.where(nan, 0, a).view(np.uint64), np.where(nan, 0, b).view(np.uint64))
+
+
+def check_scene(data, w, h, rows, textures=None, hoist=True):
+    tape = M.Scene(data).lower(hoist_rows=hoist)
+    o = OScene(data)
+    for y0, y1 in rows:
+        got = tape_eval.render_rows(tape, w, y0, y1, textures)
+        want8, want64 = o.render_rows(w, h, y0, y1, textures)
+        assert same_f64(got, want64)
+        assert np.array_equal(tape_eval.cast_u8(got), want8)
+    return tape
+
+
+def test_reader_matches_reference_fixture(chess_bytes):
+    s = M.Scene(chess_bytes)
+    assert s.size == (1024, 1024) and s.legacy
+    assert [s.node_count(c) for c in range(3)] == [29314] * 3
+    # save() re-encodes in the current numbering: equal to the test encoder's output
+    (w, h), color = decode(chess_bytes)
+    assert s.encode() == encode((w, h), color)
+    # and the result is read back as a current-numbering file
+    s2 = M.Scene(s.encode())
+    assert not s2.legacy and s2.node_count(0) == 29314
+
+
+def test_reader_errors():
+    with pytest.raises(M.MarayError) as e:
+        M.Scene(b'\x00' * 7)
+    assert e.value.code == -3
+    with pytest.raises(M.MarayError):
+        M.Scene(encode((2, 2), [x(), x(), x()]) + b'\x01')
+    with pytest.raises(M.MarayError) as e:
+        M.Scene(path='/nonexistent/file.maray')
+    assert e.value.code == -2
+
+
+def test_fix_color_matches_oracle(chess_bytes):
+    cases = [chess_bytes]
+    nested = lambda i0, d0, i1, d1, b: let_([(i0, d0)], let_([(i1, d1)], var_id(b)))
+    cases.append(encode((1, 1), [nested(0, sub(x(), nat(k)), 0, add(y(), nat(k)), 0) for k in (1, 2, 3)]))
+    cases.append(encode((1, 1), [arc(nested(0, x(), 0, y(), 0)), decor(nested(0, x(), 0, y(), 0), ['t', 3]), x()]))
+    for data in cases:
+        s = M.Scene(data); s.fix_color()
+        o = OScene(data); o.fix_color()
+        (w, h), _ = decode(data)
+        import struct
+        assert s.encode() == struct.pack('<II', w, h) + b''.join(o.encode_channel(c) for c in range(3))
+
+
+def test_chess_tape_census(chess_bytes):
+    info = M.Scene(chess_bytes).lower().info
+    # 535 constant ops folded on the host; Y-only ops hoisted
+    assert info['folded_ops'] == 535
+    assert info['alg_ops'] == info['alg_ops_xy'] + info['alg_ops_x'] + info['alg_ops_y'] + info['alg_ops_uniform']
+    assert info['n_pix_ops'] == info['alg_ops_xy'] + info['alg_ops_x'] + 3
+    assert info['n_row_ops'] == info['alg_ops_y'] + info['n_yvals']
+    assert info['n_pix_slots'] <= 32            # Sethi-Ullman order keeps few values live
+    assert info['op_histogram'][tape_eval.OP['SIN']] == 256
+    assert info['op_histogram'][tape_eval.OP['OUT']] == 3
+    plain = M.Scene(chess_bytes).lower(plain_cse=True).info
+    assert plain['alg_ops_y'] == 844            # Y-only census of SURVEY.md §8(d)
+    assert plain['alg_ops'] >= info['alg_ops']
+
+
+@pytest.mark.parametrize('hoist', [True, False])
+def test_chess_tape_equals_oracle_on_rows(chess_bytes, hoist):
+    check_scene(chess_bytes, 1024, 1024, [(0, 1), (511, 513), (600, 601), (704, 705)], hoist=hoist)
+
+
+def test_rescaled_chess_reproduces_original_pixels(chess_bytes):
+    """Config 3 cross-check: X -> X/4, Y -> Y/4 is exact, so pixel (4i,4j) of
+    the 4096^2 scene equals pixel (i,j) of the stored scene bit for bit."""
+    s = M.Scene(chess_bytes)
+    s.rescale(4, 4)
+    assert s.size == (4096, 4096)
+    big = s.lower()
+    small = M.Scene(chess_bytes).lower()
+    a = tape_eval.render_rows(big, 4096, 2400, 2401)[:, ::4]
+    b = tape_eval.render_rows(small, 1024, 600, 601)
+    assert same_f64(a, b)
+    # the same rescale done by the test builders gives the same file
+    (w, h), color = decode(chess_bytes)
+    q = [mul(x(), recip(nat(4))), mul(y(), recip(nat(4)))]
+    want = encode((4096, 4096), [subst_xy_deep(c, q) for c in color])
+    assert s.encode() == want
+    # and the oracle agrees with the tape on the rescaled scene
+    o = OScene(want)
+    _, w64 = o.render_rows(4096, 4096, 2400, 2401)
+    assert same_f64(tape_eval.render_rows(big, 4096, 2400, 2401), w64)
+
+
+def test_synthetic_scenes_equal_oracle():
+    check_scene(encode((64, 64), scenes.radial_gradient()), 64, 64, [(0, 64)])
+    check_scene(encode((96, 64), scenes.all_ops(96, 64)), 96, 64, [(0, 64)])
+    tex = scenes.textures(scale=16)
+    check_scene(encode((300, 40), scenes.textured(300)), 300, 40, [(0, 40)], textures=tex)
+
+
+def test_corner_cases_equal_oracle():
+    nanv = var_id(99)                                       # unknown variable -> NaN (src/cache.rs:40)
+    c = [max_(nanv, x()), min_(mul(nanv, y()), nat(7)), step(sub(x(), y()))]
+    check_scene(encode((16, 16), c), 16, 16, [(0, 16)])
+    # constant-only and leaf-only channels, shared Let across channels, nested Lets
+    shared = let_([(0, add(x(), nat(1))), (1, mul(var_id(0), y()))], add(var_id(1), var_id(0)))
+    c = [nat(200), y(), div(shared, nat(3))]
+    check_scene(encode((8, 8), c), 8, 8, [(0, 8)])
+    inner = let_([(5, y())], add(var_id(5), var_id(0)))     # Var(0) unknown in the inner ctx -> NaN
+    check_scene(encode((8, 8), [x(), x(), x()]), 8, 8, [(0, 8)])
+    with pytest.raises(M.MarayError) as e:                  # id 0 resolves to X outside and NaN inside
+        M.Scene(encode((8, 8), [let_([(0, x())], add(inner, var_id(0))), x(), x()])).lower()
+    assert e.value.code == -4
+    with pytest.raises(M.MarayError) as e:                  # self-referential definition
+        M.Scene(encode((8, 8), [let_([(0, add(var_id(0), nat(1)))], var_id(0)), x(), x()])).lower()
+    assert e.value.code == -5
+    # sin of a constant is not folded on the host
+    t = M.Scene(encode((8, 8), [sin(nat(1)), x(), x()])).lower()
+    assert t.info['folded_ops'] == 0 and t.info['alg_ops_uniform'] == 1
+    check_scene(encode((8, 8), [sin(nat(1)), x(), x()]), 8, 8, [(0, 8)])
+
+
+def test_app_range_is_checked_at_context_creation():
+    t = M.Scene(encode((8, 8), [scenes.textured(8)[0], x(), x()])).lower()
+    assert t.info['n_app'] == 6
+    with pytest.raises(M.MarayError) as e:
+        M.Context(t, textures=None)
+    assert e.value.code in (-6,)
