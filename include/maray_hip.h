@@ -85,7 +85,8 @@ typedef struct maray_lower_opts {
     uint32_t hoist_rows;   /* 1 = hoist Y-only sub-expressions into the ROW section (default), 0 = off */
     uint32_t plain_cse;    /* 1 = hash-cons without commutative operand canonicalisation (reproduces the
                               op census of SURVEY.md §8(d)); 0 = canonicalise a+b/b+a etc. (default) */
-    uint32_t reserved[6];
+    uint32_t no_fuse;      /* 1 = keep Step(Sin(a)) as two ops; 0 = fuse into MARAY_OP_STEPSIN (default) */
+    uint32_t reserved[5];
 } maray_lower_opts;
 
 typedef struct maray_tape_info {
@@ -96,6 +97,7 @@ typedef struct maray_tape_info {
     uint32_t folded_ops;       /* constant ops folded on the host */
     uint32_t dag_nodes;        /* unique DAG nodes including leaves */
     uint32_t acc_operands;     /* operand reads served by ACC */
+    uint32_t sin_ops, sin_bounded;   /* Sin/StepSin ops, and how many have a proven-bounded argument */
     uint32_t op_histogram[MARAY_OP_COUNT];   /* PIXEL section */
 } maray_tape_info;
 
@@ -146,6 +148,10 @@ int maray_hip_render_rows_device(maray_ctx *c, uint32_t w, uint32_t h, uint32_t 
  * the launch stream; returns the average milliseconds per launch. */
 int maray_hip_time_rows(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
                         void *d_rgb8, void *d_rgb64, int reps, float *ms_avg);
+/* MARAY_BACKEND_JIT, offline: the HIP source generated for a tape (free with
+ * maray_free) and the gfx950 code object hiprtc builds from it (needs no GPU). */
+int maray_jit_source(const maray_program *prog, char **src_out);
+int maray_jit_build(const maray_program *prog, void **code_out, size_t *len_out);
 /* Name of the dominant kernel (for matching rocprofv3 rows). */
 const char *maray_hip_kernel_name(const maray_ctx *c);
 

@@ -19,7 +19,8 @@
  * One op = one 64-bit little-endian word:
  *
  *   bits  0..6   opcode   (MARAY_OP_*)
- *   bits  7..19  aux      (OUT: output index; APP/TEXDIM: function id)
+ *   bits  7..19  aux      (OUT: output index; APP/TEXDIM: function id;
+ *                         SIN/STEPSIN: bit 0 = MARAY_AUX_SIN_BOUNDED)
  *   bits 20..31  dst      (value slot written, or MARAY_DST_NONE)
  *   bits 32..47  a        (operand reference)
  *   bits 48..63  b        (operand reference; 0 for unary ops)
@@ -60,8 +61,15 @@ enum {
     MARAY_OP_APP = 14,    /* :664-668 with textures::functions (src/textures.rs:54-65), aux = id, id % 5 < 3 */
     MARAY_OP_TEXDIM = 15, /* App with id % 5 in {3,4}: image width / height (src/textures.rs:40-50), aux = id */
     MARAY_OP_OUT = 16,    /* output[aux] = a */
-    MARAY_OP_COUNT = 17
+    MARAY_OP_STEPSIN = 17, /* Step(Sin(a)) fused: :644-648; only the sign of glibc's sin is computed */
+    MARAY_OP_COUNT = 18
 };
+
+/* SIN / STEPSIN aux bit 0: the lowering proved by interval arithmetic that the
+ * argument is finite with |a| < 105414350 (glibc's reduce_sincos range) for every
+ * pixel with x, y < MARAY_DOMAIN_MAX, so the huge-argument path cannot be taken. */
+#define MARAY_AUX_SIN_BOUNDED 1u
+#define MARAY_DOMAIN_MAX 1048576u
 
 #define MARAY_DST_NONE 0xFFFu
 #define MARAY_MAX_SLOTS 0xFFFu

@@ -93,7 +93,7 @@ void validate_program(const maray_program &p)
             const uint32_t op = MARAY_INS_OP(ins), aux = MARAY_INS_AUX(ins), dst = MARAY_INS_DST(ins);
             if (op >= MARAY_OP_COUNT) throw Error{MARAY_E_ARG, "invalid opcode at op " + std::to_string(i)};
             if (op == MARAY_OP_NOP) continue;
-            const int arity = (op == MARAY_OP_TEXDIM) ? 0 : (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) ? 2 : 1;
+            const int arity = (op == MARAY_OP_TEXDIM) ? 0 : (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) ? 2 : 1;   // STEPSIN, OUT, MOV and the unary ops read `a` only
             const uint32_t refs[2] = {MARAY_INS_A(ins), MARAY_INS_B(ins)};
             for (int k = 0; k < arity; k++) {
                 const uint32_t kind = MARAY_REF_KIND(refs[k]), idx = MARAY_REF_INDEX(refs[k]);
@@ -328,6 +328,31 @@ int maray_hip_time_rows(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uint3
         check_rows(w, h, y0, y1);
         REQUIRE(y1 > y0 && w > 0 && reps > 0, "empty launch");
         *ms_avg = c->backend->time_rows(w, h, y0, y1, d_rgb8, d_rgb64, reps);
+    });
+}
+
+int maray_jit_source(const maray_program *prog, char **src_out)
+{
+    return guard([&] {
+        REQUIRE(prog && src_out, "null argument");
+        const std::string s = jit_source(*prog);
+        *src_out = (char *)malloc(s.size() + 1);
+        if (!*src_out) throw Error{MARAY_E_INTERNAL, "out of memory"};
+        memcpy(*src_out, s.c_str(), s.size() + 1);
+    });
+}
+
+int maray_jit_build(const maray_program *prog, void **code_out, size_t *len_out)
+{
+    return guard([&] {
+        REQUIRE(prog && code_out && len_out, "null argument");
+        std::vector<char> code;
+        std::string log;
+        jit_compile(jit_source(*prog), code, log);
+        *code_out = malloc(code.size() ? code.size() : 1);
+        if (!*code_out) throw Error{MARAY_E_INTERNAL, "out of memory"};
+        memcpy(*code_out, code.data(), code.size());
+        *len_out = code.size();
     });
 }
 

@@ -3,6 +3,7 @@
 
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "expr.hpp"
 #include "maray_hip.h"
@@ -18,12 +19,22 @@ struct Backend {
     // average ms per launch of the pixel kernel, HIP events on the launch stream
     virtual float time_rows(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, void *d8, void *d64, int reps) = 0;
     virtual const char *kernel_name() const = 0;
+    // Tape interpreter only: re-evaluate the 256-pixel tiles whose flag word is
+    // non-zero (tile = row_in_launch * ceil(w/256) + x/256), reading the row values
+    // from `yvals` instead of running the ROW section.  Enqueued on `stream`.
+    virtual void render_flagged(uint32_t, uint32_t, uint32_t, void *, void *, void *, const unsigned *, const double *) {
+        throw Error{MARAY_E_INTERNAL, "render_flagged is not supported by this backend"};
+    }
 };
 
 void set_last_error(const std::string &m);   // thread-local message behind maray_last_error()
 int hip_device_count();
 Backend *make_tape_backend(int device, const maray_program &prog, const maray_texture *tex, uint32_t n_tex, bool lds_variant);
 Backend *make_jit_backend(int device, const maray_program &prog, const maray_texture *tex, uint32_t n_tex);
+std::string jit_source(const maray_program &prog);        // PIXEL kernel source; throws Error
+std::string jit_source_rows(const maray_program &prog);   // ROW kernel source
+void jit_compile(const std::string &src, std::vector<char> &code, std::string &log);     // hiprtc, gfx950; throws Error
+void validate_program(const maray_program &p);
 
 }   // namespace maray
 

@@ -24,6 +24,10 @@ MARAY_DEV double mr_min(double a, double b) { return __builtin_fmin(a, b); }
 // Sin Exp Ln (:648-650): the platform libm of the reference host = glibc 2.35
 // x86_64 FMA variants, reproduced bit for bit (maray_libm.h).
 MARAY_DEV double mr_sin(double a) { return maray_libm_sin(a); }
+MARAY_DEV double mr_stepsin(double a) { return maray_libm_step_sin(a); }
+MARAY_DEV double mr_stepsin_fast(double a, float *defer) { return maray_libm_step_sin_fast(a, defer); }
+MARAY_DEV double mr_stepsin_bounded(double a) { return maray_libm_step_sin_bounded(a); }
+MARAY_DEV double mr_sin_bounded(double a) { return maray_libm_sin_bounded(a); }
 MARAY_DEV double mr_exp(double a) { return maray_libm_exp(a); }
 MARAY_DEV double mr_ln(double a) { return maray_libm_log(a); }
 

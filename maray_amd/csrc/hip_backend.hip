@@ -42,6 +42,7 @@ struct KArgs {
     double *yout;              // ROW: rows x n_yvals
     double *spill;             // [slot - n_lds_slots][grid_threads]
     const MarayTex *tex;
+    const unsigned *tile_flags;   // optional: only tiles with a non-zero word are evaluated
     unsigned char *rgb8;
     double *rgb64;
     uint32_t n_ops, n_consts, n_yvals, n_slots, n_lds_slots;
@@ -98,6 +99,7 @@ __device__ __forceinline__ void run_tape(const KArgs &A, const uint64_t *tape_ld
         case MARAY_OP_SQRT: r = mr_sqrt(fetch(ra)); break;
         case MARAY_OP_STEP: r = mr_step(fetch(ra)); break;
         case MARAY_OP_SIN: r = mr_sin(fetch(ra)); break;
+        case MARAY_OP_STEPSIN: r = mr_stepsin(fetch(ra)); break;
         case MARAY_OP_EXP: r = mr_exp(fetch(ra)); break;
         case MARAY_OP_LN: r = mr_ln(fetch(ra)); break;
         case MARAY_OP_ADD: { const double a = fetch(ra), b = fetch(rb); r = a + b; break; }
@@ -148,6 +150,7 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_pixels(const KArgs A)
     double *spill_base = A.spill ? A.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
 
     for (uint32_t tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
+        if (A.tile_flags && !A.tile_flags[tile]) continue;                 // wave-uniform
         const uint32_t r = tile / A.tiles_per_row;                 // row within this launch (uniform)
         const uint32_t x = (tile - r * A.tiles_per_row) * BLOCK + threadIdx.x;
         const uint32_t y = A.y0 + r;
@@ -209,11 +212,11 @@ struct TapeBackend final : Backend {
     std::string kname;
 
     ~TapeBackend() override {
-        hipSetDevice(device);
-        hipFree(d_row_ops); hipFree(d_pix_ops); hipFree(d_consts); hipFree(d_tex);
-        for (auto p : d_tex_rgb) hipFree(p);
-        hipFree(d_yvals); hipFree(d_spill); hipFree(d_rgb8); hipFree(d_rgb64);
-        if (own_stream) hipStreamDestroy(own_stream);
+        (void)hipSetDevice(device);
+        (void)hipFree(d_row_ops); (void)hipFree(d_pix_ops); (void)hipFree(d_consts); (void)hipFree(d_tex);
+        for (auto p : d_tex_rgb) (void)hipFree(p);
+        (void)hipFree(d_yvals); (void)hipFree(d_spill); (void)hipFree(d_rgb8); (void)hipFree(d_rgb64);
+        if (own_stream) (void)hipStreamDestroy(own_stream);
     }
 
     void init(int dev, const maray_program &prog, const maray_texture *tex, uint32_t n_tex, bool lds_variant) {
@@ -272,11 +275,13 @@ struct TapeBackend final : Backend {
         cap = n;
     }
 
-    void launch(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, unsigned char *d8, double *d64, hipStream_t st, bool rows_pass) {
+    void launch(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, unsigned char *d8, double *d64, hipStream_t st, bool rows_pass,
+                const unsigned *tile_flags = nullptr, const double *ext_yvals = nullptr) {
         (void)h;
         const uint32_t rows = y1 - y0;
         if (!rows || !w) return;
-        ensure(d_yvals, yvals_cap, (size_t)rows * std::max<uint32_t>(P.n_yvals, 1));
+        if (!ext_yvals) ensure(d_yvals, yvals_cap, (size_t)rows * std::max<uint32_t>(P.n_yvals, 1));
+        if (ext_yvals) rows_pass = false;
         if (rows_pass && P.n_row_ops) {
             KArgs R{};
             R.tape = d_row_ops; R.consts = d_consts; R.yout = d_yvals; R.tex = d_tex;
@@ -292,7 +297,8 @@ struct TapeBackend final : Backend {
             HIP_TRY(hipGetLastError());
         }
         KArgs A{};
-        A.tape = d_pix_ops; A.consts = d_consts; A.yvals = d_yvals; A.tex = d_tex;
+        A.tape = d_pix_ops; A.consts = d_consts; A.yvals = ext_yvals ? ext_yvals : d_yvals; A.tex = d_tex;
+        A.tile_flags = tile_flags;
         A.rgb8 = d8; A.rgb64 = d64;
         A.n_ops = P.n_pix_ops; A.n_consts = P.n_consts; A.n_yvals = P.n_yvals;
         A.n_slots = P.n_pix_slots; A.n_lds_slots = n_lds_slots;
@@ -314,6 +320,12 @@ struct TapeBackend final : Backend {
     void render_device(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, void *d8, void *d64, void *stream) override {
         HIP_TRY(hipSetDevice(device));
         launch(w, h, y0, y1, (unsigned char *)d8, (double *)d64, (hipStream_t)stream, true);
+    }
+
+    void render_flagged(uint32_t w, uint32_t y0, uint32_t y1, void *d8, void *d64, void *stream, const unsigned *flags,
+                        const double *yvals) override {
+        HIP_TRY(hipSetDevice(device));
+        launch(w, 0, y0, y1, (unsigned char *)d8, (double *)d64, (hipStream_t)stream, false, flags, yvals);
     }
 
     void render_host(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint8_t *rgb8, double *rgb64) override {
@@ -342,7 +354,7 @@ struct TapeBackend final : Backend {
         HIP_TRY(hipEventSynchronize(e1));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        hipEventDestroy(e0); hipEventDestroy(e1);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         return ms / (float)(reps > 0 ? reps : 1);
     }
 

@@ -77,6 +77,7 @@ struct Dag {
     std::unordered_map<std::array<uint64_t, 3>, int32_t, KeyHash> map;
     uint32_t folded = 0;
     bool commute = true;
+    bool fuse = true;
 
     int32_t intern(const DNode &d) {
         std::array<uint64_t, 3> k = {(uint64_t)d.op | ((uint64_t)d.aux << 8), ((uint64_t)(uint32_t)d.a << 32) | (uint32_t)d.b,
@@ -106,6 +107,8 @@ struct Dag {
             default: break;   // sin / exp / ln are evaluated on the device only
             }
         }
+        if (fuse && op == MARAY_OP_STEP && n[a].op == MARAY_OP_SIN)   // Step(Sin(t)): only the sign of sin is observable here
+            return intern(DNode{MARAY_OP_STEPSIN, n[n[a].a].dep, 0, n[a].a, -1, 0.0});
         return intern(DNode{op, n[a].dep, 0, a, -1, 0.0});
     }
     int32_t binary(uint8_t op, int32_t a, int32_t b) {
@@ -203,6 +206,79 @@ struct SymEval {
     }
 };
 
+// ---- interval analysis ----------------------------------------------------------------
+// Conservative bounds of every DAG node over the pixel domain x, y in
+// [0, MARAY_DOMAIN_MAX): used to prove that the argument of a Sin stays inside
+// glibc's reduce_sincos range (so the specialised kernels need no huge-argument
+// path for that op).  Bounds are widened by one ulp per operation; `nan` marks
+// values that may be NaN.
+struct Ival {
+    double lo, hi;
+    bool nan;
+};
+
+inline double down(double v) { return std::nextafter(v, -INFINITY); }
+inline double up(double v) { return std::nextafter(v, INFINITY); }
+
+Ival ival_mul(const Ival &a, const Ival &b)
+{
+    Ival r{INFINITY, -INFINITY, a.nan || b.nan};
+    const double xs[2] = {a.lo, a.hi}, ys[2] = {b.lo, b.hi};
+    for (double x : xs) for (double y : ys) {
+        const double p = x * y;
+        if (p != p) { r.nan = true; r.lo = -INFINITY; r.hi = INFINITY; continue; }   // 0 * inf
+        r.lo = std::min(r.lo, p); r.hi = std::max(r.hi, p);
+    }
+    r.lo = down(r.lo); r.hi = up(r.hi);
+    return r;
+}
+
+std::vector<Ival> intervals(const Dag &g)
+{
+    const double dmax = (double)MARAY_DOMAIN_MAX - 1.0;
+    std::vector<Ival> v(g.n.size());
+    for (size_t i = 0; i < g.n.size(); i++) {        // children are interned before their parents
+        const DNode &d = g.n[i];
+        const Ival a = d.a >= 0 ? v[d.a] : Ival{0, 0, false};
+        const Ival b = d.b >= 0 ? v[d.b] : Ival{0, 0, false};
+        Ival r{-INFINITY, INFINITY, true};
+        switch (d.op) {
+        case D_CONST: r = (d.cval != d.cval) ? Ival{-INFINITY, INFINITY, true} : Ival{d.cval, d.cval, false}; break;
+        case D_X: case D_Y: r = Ival{0.0, dmax, false}; break;
+        case MARAY_OP_MOV: r = a; break;
+        case MARAY_OP_NEG: r = Ival{-a.hi, -a.lo, a.nan}; break;
+        case MARAY_OP_ABS:
+            r = (a.lo >= 0) ? a : (a.hi <= 0 ? Ival{-a.hi, -a.lo, a.nan} : Ival{0.0, std::max(-a.lo, a.hi), a.nan});
+            break;
+        case MARAY_OP_RECIP:
+            if (a.lo > 0 || a.hi < 0) r = Ival{down(1.0 / a.hi), up(1.0 / a.lo), a.nan};
+            else r = Ival{-INFINITY, INFINITY, a.nan};
+            break;
+        case MARAY_OP_SQRT: r = Ival{a.lo > 0 ? down(std::sqrt(a.lo)) : 0.0, a.hi > 0 ? up(std::sqrt(a.hi)) : 0.0, a.nan || a.lo < 0}; break;
+        case MARAY_OP_STEP: case MARAY_OP_STEPSIN: r = Ival{0.0, 1.0, false}; break;
+        case MARAY_OP_SIN: r = Ival{-1.0, 1.0, a.nan || std::isinf(a.lo) || std::isinf(a.hi)}; break;
+        case MARAY_OP_EXP: r = Ival{std::max(0.0, down(std::exp(a.lo) * (1 - 0x1p-50))), up(std::exp(a.hi) * (1 + 0x1p-50)), a.nan}; break;
+        case MARAY_OP_LN:
+            r = Ival{a.lo > 0 ? down(std::log(a.lo) - 0x1p-40) : -INFINITY, a.hi > 0 ? up(std::log(a.hi) + 0x1p-40) : -INFINITY, a.nan || a.lo < 0};
+            break;
+        case MARAY_OP_ADD: {
+            const double lo = a.lo + b.lo, hi = a.hi + b.hi;
+            r = Ival{lo != lo ? -INFINITY : down(lo), hi != hi ? INFINITY : up(hi), a.nan || b.nan || lo != lo || hi != hi ||
+                     (std::isinf(a.lo) && std::isinf(b.hi)) || (std::isinf(a.hi) && std::isinf(b.lo))};
+            break;
+        }
+        case MARAY_OP_MUL: r = ival_mul(a, b); break;
+        case MARAY_OP_MAX: r = Ival{std::max(a.lo, b.lo), std::max(a.hi, b.hi), a.nan && b.nan}; if (a.nan || b.nan) { r.lo = std::min(a.lo, b.lo); } break;
+        case MARAY_OP_MIN: r = Ival{std::min(a.lo, b.lo), std::min(a.hi, b.hi), a.nan && b.nan}; if (a.nan || b.nan) { r.hi = std::max(a.hi, b.hi); } break;
+        case MARAY_OP_APP: r = Ival{0.0, 255.0, false}; break;
+        case MARAY_OP_TEXDIM: r = Ival{0.0, 4294967295.0, false}; break;
+        default: break;
+        }
+        v[i] = r;
+    }
+    return v;
+}
+
 // ---- section scheduling + encoding --------------------------------------------------
 struct Section {
     std::vector<int32_t> order;                 // computing nodes in schedule order
@@ -214,6 +290,7 @@ struct Section {
 
 struct Lowerer {
     const Dag &g;
+    std::vector<uint8_t> sin_bounded;           // per node: Sin/StepSin argument proven inside reduce_sincos range
     std::vector<uint8_t> in_section;            // node belongs to the section being built
     std::vector<int32_t> need;                  // Sethi-Ullman label
     std::vector<uint8_t> visited;
@@ -363,7 +440,9 @@ struct Lowerer {
             uint32_t dst = MARAY_DST_NONE;
             if (first_far_use[it.node]) { dst = alloc(); slot[it.node] = (int32_t)dst; }
             if (d.aux > 0x1FFFu) throw Error{MARAY_E_LIMIT, "App id above 8191"};
-            sec.ops.push_back(MARAY_INS(d.op, d.aux, dst, a, b));
+            uint32_t aux = d.aux;
+            if ((d.op == MARAY_OP_SIN || d.op == MARAY_OP_STEPSIN) && sin_bounded[it.node]) aux |= MARAY_AUX_SIN_BOUNDED;
+            sec.ops.push_back(MARAY_INS(d.op, aux, dst, a, b));
         }
         sec.n_slots = next_slot;
     }
@@ -378,6 +457,7 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
 
     Dag g;
     g.commute = opts.plain_cse == 0;
+    g.fuse = opts.no_fuse == 0;
     SymEval ev(s, g);
     int32_t roots[3];
     for (int c = 0; c < 3; c++) roots[c] = ev.eval(s.color[c], -1);   // outer Context::new() is empty (src/render.rs:53)
@@ -405,18 +485,29 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         if (!reach[i]) continue;
         info.dag_nodes++;
         if (!is_op((int32_t)i)) continue;
-        info.alg_ops++;
+        const uint32_t cnt = g.n[i].op == MARAY_OP_STEPSIN ? 2u : 1u;   // a fused op stands for two Expr ops
+        info.alg_ops += cnt;
         switch (g.n[i].dep) {
-        case 0: info.alg_ops_uniform++; break;
-        case DEP_X: info.alg_ops_x++; break;
-        case DEP_Y: info.alg_ops_y++; break;
-        default: info.alg_ops_xy++;
+        case 0: info.alg_ops_uniform += cnt; break;
+        case DEP_X: info.alg_ops_x += cnt; break;
+        case DEP_Y: info.alg_ops_y += cnt; break;
+        default: info.alg_ops_xy += cnt;
         }
         if (g.n[i].op == MARAY_OP_APP || g.n[i].op == MARAY_OP_TEXDIM) max_app = std::max(max_app, g.n[i].aux + 1);
     }
     info.n_app = max_app;
 
     Lowerer L(g);
+    {
+        const std::vector<Ival> iv = intervals(g);
+        L.sin_bounded.assign(N, 0);
+        for (size_t i = 0; i < N; i++) {
+            if (!reach[i] || (g.n[i].op != MARAY_OP_SIN && g.n[i].op != MARAY_OP_STEPSIN)) continue;
+            const Ival &a = iv[g.n[i].a];
+            if (!a.nan && std::max(std::fabs(a.lo), std::fabs(a.hi)) < 105414350.0) { L.sin_bounded[i] = 1; info.sin_bounded++; }
+            info.sin_ops++;
+        }
+    }
     const bool hoist = opts.hoist_rows != 0;
     // ROW section: reachable ops that do not depend on X.
     Section row, pix;

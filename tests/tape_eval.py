@@ -10,7 +10,7 @@ import math
 import numpy as np
 
 OP = dict(NOP=0, MOV=1, NEG=2, ABS=3, RECIP=4, SQRT=5, STEP=6, SIN=7, EXP=8, LN=9, ADD=10, MUL=11, MAX=12, MIN=13,
-          APP=14, TEXDIM=15, OUT=16)
+          APP=14, TEXDIM=15, OUT=16, STEPSIN=17)
 K_SLOT, K_CONST, K_YVAL, K_SPEC = 0, 1, 2, 3
 DST_NONE = 0xFFF
 
@@ -74,6 +74,7 @@ def run_section(ops, consts, n_slots, X, Y, yvals, textures, n_out):
             elif op == OP['SQRT']: r = np.sqrt(fetch(ra))
             elif op == OP['STEP']: r = np.where(fetch(ra) >= 0.0, 1.0, 0.0)
             elif op == OP['SIN']: r = _sin(fetch(ra))
+            elif op == OP['STEPSIN']: r = np.where(_sin(fetch(ra)) >= 0.0, 1.0, 0.0)
             elif op == OP['EXP']: r = _vexp(fetch(ra))
             elif op == OP['LN']: r = _vlog(fetch(ra))
             elif op == OP['ADD']: r = fetch(ra) + fetch(rb)

@@ -17,7 +17,7 @@ from test_lowering import same_f64
 
 pytestmark = pytest.mark.gpu
 
-BACKENDS = [M.BACKEND_TAPE, M.BACKEND_TAPE_SMEM]
+BACKENDS = [M.BACKEND_TAPE, M.BACKEND_TAPE_SMEM, M.BACKEND_JIT]
 
 
 def gpu_vs_oracle(data, w, h, rows, textures=None, backends=BACKENDS, hoist=True):
@@ -95,6 +95,38 @@ def test_textured_scene(chess_bytes):
     tex = scenes.textures(scale=4)
     data = encode((1024, 256), scenes.textured(1024))
     gpu_vs_oracle(data, 1024, 256, [(0, 256)], textures=tex)
+
+
+def test_all_ops_scene_bit_exact():
+    """Config 3b: every computing variant of Expr (sin, exp, ln, sqrt, abs, recip ...) - f64 planes bit-exact."""
+    data = encode((640, 96), scenes.all_ops(640, 96))
+    gpu_vs_oracle(data, 640, 96, [(0, 96)])
+    data = encode((4096, 4096), scenes.all_ops(4096, 4096))
+    gpu_vs_oracle(data, 4096, 4096, [(0, 2), (2047, 2049), (4094, 4096)], backends=[M.BACKEND_JIT, M.BACKEND_TAPE_SMEM])
+
+
+def test_libm_sweep_through_the_kernels():
+    """sin / exp / ln / step(sin) over 2^-40 .. 2^40 x [-300, 300] — glibc bit for bit (oracle calls the system libm)."""
+    from marayb import exp, ln, sin
+    v = mul(sub(x(), nat(300)), exp(mul(sub(y(), nat(40)), ln(nat(2)))))      # (x - 300) * 2^(y - 40)
+    c = [sin(v), exp(mul(v, div(nat(1), nat(64)))), ln(abs_(v))]
+    gpu_vs_oracle(encode((600, 81), c), 600, 81, [(0, 81)])
+    c = [step(sin(v)), step(sin(add(v, nat(1)))), sin(mul(v, v))]
+    gpu_vs_oracle(encode((600, 81), c), 600, 81, [(0, 81)])
+
+
+def test_sin_of_huge_inf_and_nan_arguments():
+    """Arguments beyond glibc's reduce_sincos range (|a| >= 105414350), inf and NaN: the specialised
+    kernels defer those tiles to the interpreter kernel; results stay bit-exact."""
+    from marayb import exp, ln, sin
+    big = mul(x(), nat(10 ** 9))
+    c = [sin(add(big, y())), step(sin(mul(big, add(y(), nat(1))))), sin(exp(x()))]                # exp(x) -> inf -> sin = NaN
+    t = M.Scene(encode((1000, 4), c)).lower()
+    assert t.info['sin_bounded'] == 0 and t.info['sin_ops'] == 3
+    gpu_vs_oracle(encode((1000, 4), c), 1000, 4, [(0, 4)])
+    # only some tiles are huge: x * 2^20 crosses 105414350 at x ~ 100
+    c = [step(sin(mul(x(), nat(1 << 20)))), sin(mul(x(), nat(1 << 20))), sin(ln(sub(x(), nat(500))))]   # ln(<0) = NaN
+    gpu_vs_oracle(encode((1000, 3), c), 1000, 3, [(0, 3)])
 
 
 def test_corner_cases():

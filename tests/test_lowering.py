@@ -74,10 +74,15 @@ def test_chess_tape_census(chess_bytes):
     # 535 constant ops folded on the host; Y-only ops hoisted
     assert info['folded_ops'] == 535
     assert info['alg_ops'] == info['alg_ops_xy'] + info['alg_ops_x'] + info['alg_ops_y'] + info['alg_ops_uniform']
-    assert info['n_pix_ops'] == info['alg_ops_xy'] + info['alg_ops_x'] + 3
+    fused = info['op_histogram'][tape_eval.OP['STEPSIN']]
+    assert fused == 256                       # every Sin of chess feeds a Step (SURVEY.md finding 4)
+    assert info['n_pix_ops'] == info['alg_ops_xy'] + info['alg_ops_x'] + 3 - fused   # a fused op stands for two
     assert info['n_row_ops'] == info['alg_ops_y'] + info['n_yvals']
     assert info['n_pix_slots'] <= 32            # Sethi-Ullman order keeps few values live
-    assert info['op_histogram'][tape_eval.OP['SIN']] == 256
+    assert info['op_histogram'][tape_eval.OP['SIN']] == 0
+    unfused = M.Scene(chess_bytes).lower(fuse=False).info
+    assert unfused['op_histogram'][tape_eval.OP['SIN']] == 256 and unfused['alg_ops'] == info['alg_ops']
+    assert info['sin_ops'] == info['sin_bounded'] == 256      # interval analysis: |arg| < 105414350 everywhere
     assert info['op_histogram'][tape_eval.OP['OUT']] == 3
     plain = M.Scene(chess_bytes).lower(plain_cse=True).info
     assert plain['alg_ops_y'] == 844            # Y-only census of SURVEY.md §8(d)
@@ -87,6 +92,12 @@ def test_chess_tape_census(chess_bytes):
 @pytest.mark.parametrize('hoist', [True, False])
 def test_chess_tape_equals_oracle_on_rows(chess_bytes, hoist):
     check_scene(chess_bytes, 1024, 1024, [(0, 1), (511, 513), (600, 601), (704, 705)], hoist=hoist)
+
+
+def test_unfused_chess_tape_equals_oracle(chess_bytes):
+    tape = M.Scene(chess_bytes).lower(fuse=False)
+    _, want64 = OScene(chess_bytes).render_rows(1024, 1024, 512, 513)
+    assert same_f64(tape_eval.render_rows(tape, 1024, 512, 513), want64)
 
 
 def test_rescaled_chess_reproduces_original_pixels(chess_bytes):
