@@ -57,8 +57,8 @@ def main():
     scene = M.Scene(data)
     scene.rescale(4, 4)                      # config 3: chess.maray regenerated at 4096 x 4096 (exact power-of-two rescale)
     tape = scene.lower()
-    h_total = H_TILE * n_gpus
-    y0, y1 = rank * H_TILE, (rank + 1) * H_TILE
+    from maray_amd.sharding import max_over_ranks, weak_rows
+    y0, y1, h_total = weak_rows(rank, n_gpus, H_TILE)
 
     backends = {'tape': M.BACKEND_TAPE, 'tape-smem': M.BACKEND_TAPE_SMEM, 'jit': M.BACKEND_JIT}
     order = ['jit', 'tape-smem', 'tape'] if args.backend == 'auto' else [args.backend]
@@ -95,10 +95,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dist if world > 1 else None, dt, device='cuda')
 
     px_per_step = W * H_TILE * n_gpus
     value = px_per_step * args.steps / dt / 1e6
@@ -117,16 +114,24 @@ def main():
         sub = out8[::4, ::4].contiguous().cpu().numpy()
         parity = hashlib.sha256(sub.tobytes()).hexdigest() == g['rgb8_sha256']
 
+    # HBM traffic per launch from the committed PMC profile of this very command (FETCH_SIZE x2 per the gfx950
+    # correction of MI355X_MICROARCH.md + WRITE_SIZE); bench.py cannot collect PMC counters itself.
+    traffic = None
+    prof = os.path.join(ROOT, 'profiles', 'r1_%s_chess4096_pmc.json' % backend_name)
+    if os.path.exists(prof):
+        d = json.load(open(prof))['derived']
+        traffic = d['hbm_fetch_bytes_x2_gfx950_correction'] + d['hbm_write_bytes']
+
     cpu = None
     if rank == 0 and n_gpus == 1 and args.cpu_seconds > 0:
         sys.path.insert(0, os.path.join(ROOT, 'tests'))
         from oracle_ffi import Scene as OScene
         o = OScene(scene.encode())
-        threads = os.cpu_count() or 1
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
         t = time.perf_counter()
         o.render_rows(W, H_TILE, 2048, 2048 + 2, threads=threads, want_f64=False)   # pilot: 2 rows
         pilot = time.perf_counter() - t
-        rows = int(max(threads, min(H_TILE - 2048, args.cpu_seconds / max(pilot / 2, 1e-6))))
+        rows = int(max(2, min(H_TILE - 2048, args.cpu_seconds / max(pilot / 2, 1e-6))))
         t = time.perf_counter()
         o.render_rows(W, H_TILE, 2048, 2048 + rows, threads=threads, want_f64=False)
         ct = time.perf_counter() - t
@@ -147,7 +152,7 @@ def main():
                        'tape_ops_per_pixel': tape.info['n_pix_ops'], 'parallelism': 'row tiles, no collective',
                        'bit_exact_vs_golden': parity},
             'roofline': {'bound': 'valu_f64', 'achieved': achieved, 'peak': PEAK_F64_TOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F64_TOPS, 'traffic': None,
+                         'frac': achieved / PEAK_F64_TOPS, 'traffic': traffic,
                          'kernel_ms': k_ms, 'alg_ops_per_pixel': ALG_OPS_PER_PIXEL,
                          'hbm': {'achieved': hbm_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                  'frac': hbm_gbs / PEAK_HBM_GBS, 'bytes_per_pixel': 3}},
