@@ -521,8 +521,23 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
             for (int32_t c : {g.n[i].a, g.n[i].b}) if (c >= 0 && is_row[c]) frontier[c] = 1;
         }
         for (int c = 0; c < 3; c++) if (is_row[roots[c]]) frontier[roots[c]] = 1;
+        // Number the y values in the order the PIXEL schedule first reads them, so that consecutive
+        // reads hit consecutive table entries (the specialised kernel fetches them in 64-byte scalar
+        // loads; scattered indices would keep whole batches parked in SGPRs).
+        std::vector<uint8_t> is_pix0(N, 0);
+        for (size_t i = 0; i < N; i++) if (reach[i] && is_op((int32_t)i) && !is_row[i]) is_pix0[i] = 1;
+        Section dry;
+        L.in_section = is_pix0;
+        L.need.assign(N, -1);
+        L.visited.assign(N, 0);
+        for (int c = 0; c < 3; c++) if (is_pix0[roots[c]]) L.visit(roots[c], dry);
         uint32_t k = 0;
-        for (size_t i = 0; i < N; i++) if (frontier[i]) { L.yval_of[i] = (int32_t)k; row.outs.push_back({(int32_t)i, k}); k++; }
+        auto number = [&](int32_t c) {
+            if (c >= 0 && frontier[c] && L.yval_of[c] < 0) { L.yval_of[c] = (int32_t)k; row.outs.push_back({c, k}); k++; }
+        };
+        for (int32_t nd : dry.order) { number(g.n[nd].a); number(g.n[nd].b); }
+        for (int c = 0; c < 3; c++) number(roots[c]);
+        for (size_t i = 0; i < N; i++) number((int32_t)i);
         info.n_yvals = k;
         if (k > MARAY_MAX_INDEX + 1) throw Error{MARAY_E_LIMIT, "more than 16384 row values"};
     }

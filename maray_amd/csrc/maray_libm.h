@@ -292,18 +292,25 @@ MR_FN double maray_libm_step_sin_fast(double x, float *defer)
 // this range every double is farther than 2^-70 from every multiple of pi/2
 // (tests/native/libm_check.cpp walks all 6.7e7 multiples and their neighbouring
 // doubles against glibc), so sign(a) is the sign of do_sin(a, da).
+//
+// The small-argument branches of __sin need no special case here: for
+// |x| < 2.426265 glibc returns a value with the sign of x (do_sin(x,0) /
+// copysign(do_cos(..), x); sin(x) = x below 2^-26), and the reduction below
+// yields exactly that sign (n = 0, a = x for |x| < pi/4; n odd or a = x -+ pi
+// beyond; x = -0.0 reduces to a = +0.0, matching step(-0.0) = 1).
 MR_FN double maray_libm_step_sin_bounded(double x)
 {
-    const unsigned k = (unsigned)(mr_bits(x) >> 32) & 0x7fffffffu;
     const double t = mr_fma(x, MR_HPINV, MR_TOINT);
     const double xn = t - MR_TOINT;
     const unsigned n = (unsigned)mr_bits(t);
     const double y = mr_fma(-xn, MR_MP2, mr_fma(-xn, MR_MP1, x));
     const double t2 = mr_fma(-xn, MR_PP3, y);
     const double a = mr_fma(-xn, MR_PP4, t2);
-    const bool neg_red = (((n & 1u) != 0) ? false : (mr_bits(a) >> 63) != 0) != ((n & 2u) != 0);
-    const bool one = (k < 0x400368fdu) ? (x >= 0.0) : !neg_red;
-    return one ? 1.0 : 0.0;
+    // bit 31 of s = sign of __sin(x): sign(a) in the sine quadrants, flipped in quadrants 2 and 3
+    unsigned s = (n & 1u) ? 0u : (unsigned)(mr_bits(a) >> 32);
+    s ^= n << 30;
+    const unsigned hi = ~(unsigned)((int)s >> 31) & 0x3ff00000u;      // 1.0 or 0.0
+    return mr_from_bits((unsigned long long)hi << 32);
 }
 
 // sin(x) under the same precondition: maray_libm_sin without its huge tail.
