@@ -128,13 +128,13 @@ def main():
         from oracle_ffi import Scene as OScene
         o = OScene(scene.encode())
         threads = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-        t = time.perf_counter()
-        o.render_rows(W, H_TILE, 2048, 2048 + 2, threads=threads, want_f64=False)   # pilot: 2 rows
-        pilot = time.perf_counter() - t
-        rows = int(max(2, min(H_TILE - 2048, args.cpu_seconds / max(pilot / 2, 1e-6))))
-        t = time.perf_counter()
-        o.render_rows(W, H_TILE, 2048, 2048 + rows, threads=threads, want_f64=False)
-        ct = time.perf_counter() - t
+        batch = max(16, threads // 2)              # rows per call: keeps every thread busy
+        rows, ct = 0, 0.0
+        while ct < args.cpu_seconds and 2048 + rows + batch <= H_TILE:
+            t = time.perf_counter()
+            o.render_rows(W, H_TILE, 2048 + rows, 2048 + rows + batch, threads=threads, want_f64=False)
+            ct += time.perf_counter() - t
+            rows += batch
         cpu = {'value': W * rows / ct / 1e6, 'unit': 'Mpixels/s', 'cores': threads, 'kind': 'port',
                'sample': '%d rows x %d px of the same 4096x4096 chess scene (rows 2048..%d), oracle = restated '
                          'ParallelInterpreted (src/render.rs:35-99), %.1f s' % (rows, W, 2048 + rows, ct)}

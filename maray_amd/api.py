@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 OP_COUNT = 18
-BACKEND_TAPE, BACKEND_TAPE_SMEM, BACKEND_JIT = 0, 1, 2
+BACKEND_TAPE, BACKEND_TAPE_SMEM, BACKEND_JIT, BACKEND_AUTO = 0, 1, 2, 3
 REPORT_NONE, REPORT_ROW, REPORT_DURATION_MS = 0, 1, 2
 
 
@@ -277,7 +277,7 @@ class Context:
         return lib().maray_hip_kernel_name(self._h).decode()
 
 
-def gen_to_image(scene, size=None, textures=None, backend=BACKEND_TAPE, n_devices=0, tile_rows=0, report=None,
+def gen_to_image(scene, size=None, textures=None, backend=BACKEND_AUTO, n_devices=0, tile_rows=0, report=None,
                  report_kind=REPORT_NONE, report_value=0):
     """`gen_to_image` (src/lib.rs:1177-1195) with RenderMethod::Hip → HxWx3 uint8."""
     w, h = size if size else scene.size
@@ -295,7 +295,7 @@ def gen_to_image(scene, size=None, textures=None, backend=BACKEND_TAPE, n_device
     return img
 
 
-def gen(scene, path, textures=None, backend=BACKEND_TAPE, n_devices=0, report_kind=REPORT_NONE, report_value=0):
+def gen(scene, path, textures=None, backend=BACKEND_AUTO, n_devices=0, report_kind=REPORT_NONE, report_value=0):
     """`gen` (src/lib.rs:1199-1213): render and write a PNG."""
     arr, n, keep = _textures(textures)
     go = GenOpts()

@@ -277,6 +277,13 @@ int maray_hip_ctx_create(int device, const maray_program *prog, const maray_text
         case MARAY_BACKEND_TAPE: b = make_tape_backend(device, *prog, tex, n_tex, true); break;
         case MARAY_BACKEND_TAPE_SMEM: b = make_tape_backend(device, *prog, tex, n_tex, false); break;
         case MARAY_BACKEND_JIT: b = make_jit_backend(device, *prog, tex, n_tex); break;
+        case MARAY_BACKEND_AUTO:
+            try { b = make_jit_backend(device, *prog, tex, n_tex); }
+            catch (const Error &e) {
+                if (e.code == MARAY_E_NO_DEVICE) throw;
+                b = make_tape_backend(device, *prog, tex, n_tex, false);   // still the HIP path, never a CPU fallback
+            }
+            break;
         default: throw Error{MARAY_E_ARG, "unknown backend"};
         }
         maray_ctx *c = new maray_ctx();

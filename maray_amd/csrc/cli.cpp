@@ -20,7 +20,7 @@ static void usage()
             "  -o, --output <output>        Output file `*.png`\n"
             "  -t, --textures <textures>... Texture file `*.png`\n"
             "      --gpus <n>               Number of MI355X devices (default: all)\n"
-            "      --backend <b>            tape | tape-smem | jit (default: tape)\n");
+            "      --backend <b>            auto | jit | tape | tape-smem (default: auto)\n");
 }
 
 int main(int argc, char **argv)
@@ -29,6 +29,7 @@ int main(int argc, char **argv)
     std::vector<std::string> textures;
     maray_gen_opts go;
     memset(&go, 0, sizeof go);
+    go.backend = MARAY_BACKEND_AUTO;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() -> const char * { if (i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };
@@ -42,6 +43,7 @@ int main(int argc, char **argv)
             if (b == "tape") go.backend = MARAY_BACKEND_TAPE;
             else if (b == "tape-smem") go.backend = MARAY_BACKEND_TAPE_SMEM;
             else if (b == "jit") go.backend = MARAY_BACKEND_JIT;
+            else if (b == "auto") go.backend = MARAY_BACKEND_AUTO;
             else { usage(); return 2; }
         } else if (a == "-h" || a == "--help") { usage(); return 0; }
         else { usage(); return 2; }

@@ -77,7 +77,7 @@ extern "C" int maray_gen_to_image(const maray_scene *s, const maray_texture *tex
     const uint32_t tile_rows = opts && opts->tile_rows ? opts->tile_rows : 256;
     maray_ctx_opts co;
     memset(&co, 0, sizeof co);
-    co.backend = opts ? opts->backend : MARAY_BACKEND_TAPE;
+    co.backend = opts ? opts->backend : MARAY_BACKEND_AUTO;
 
     std::vector<maray_ctx *> ctxs(n_dev, nullptr);
     for (uint32_t d = 0; d < n_dev; d++) {

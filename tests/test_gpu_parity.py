@@ -90,6 +90,50 @@ def test_chess_4096_rescaled(chess_bytes):
     assert hashlib.sha256(sub8.tobytes()).hexdigest() == g['rgb8_sha256']
 
 
+def test_chess_16384_band(chess_bytes):
+    """Config 4 (one device's share): chess rescaled x16; a band vs the oracle, and (16i,16j) == stored (i,j)."""
+    s = M.Scene(chess_bytes)
+    s.rescale(16, 16)
+    assert s.size == (16384, 16384)
+    data = s.encode()
+    gpu_vs_oracle(data, 16384, 16384, [(9600, 9601)], backends=[M.BACKEND_JIT])
+    ctx = M.Context(s.lower(), backend=M.BACKEND_JIT)
+    got8, _ = ctx.render_rows(16384, 16384, 8192, 8192 + 2048, want_f64=False)      # rows of device 4 of 8
+    ctx.close()
+    small8, _ = OScene(chess_bytes).render_rows(1024, 1024, 512, 640)
+    assert np.array_equal(got8[::16, ::16], small8)
+
+
+def test_textured_scene_full_size():
+    """Config 5: two textures (1024^2 and 2048x512, splitmix64), 4096x4096, device-side sampling."""
+    tex = scenes.textures(scale=1)
+    data = encode((4096, 4096), scenes.textured(4096))
+    gpu_vs_oracle(data, 4096, 4096, [(0, 3), (2047, 2050), (4093, 4096)], textures=tex)
+    # whole image: every output is an integer texel value; channel c of pixel (x,y) = max of the two lookups
+    ctx = M.Context(M.Scene(data).lower(), textures=tex, backend=M.BACKEND_JIT)
+    got8, _ = ctx.render_rows(4096, 4096, 0, 4096, want_f64=False)
+    ctx.close()
+    yy, xx = np.mgrid[0:4096, 0:4096]
+    a = tex[0][np.minimum(yy // 4, 1023), np.minimum(xx // 4, 1023)]
+    bx = (4096 - xx) // 2
+    b = np.where((bx < 2048)[..., None], tex[1][np.minimum(yy // 8, 511), np.minimum(bx, 2047)], 0)
+    assert np.array_equal(got8, np.maximum(a, b))
+
+
+def test_cli_renders_chess_png(tmp_path, chess_bytes):
+    import subprocess
+    from PIL import Image
+    exe = os.path.join(os.path.dirname(M.lib_path()), 'maray')
+    out = str(tmp_path / 'chess.png')
+    r = subprocess.run([exe, '-c', '8', '-i', os.path.join(GOLDEN, 'chess.maray'), '-o', out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    g = json.load(open(os.path.join(GOLDEN, 'chess_1024.json')))
+    img = np.asarray(Image.open(out).convert('RGB'))
+    assert hashlib.sha256(img.tobytes()).hexdigest() == g['rgb8_sha256']
+    r = subprocess.run([exe, '-i', '/nonexistent.maray', '-o', out], capture_output=True, text=True)
+    assert r.returncode == 1 and 'Error' in r.stderr
+
+
 def test_textured_scene(chess_bytes):
     """Config 5 at reduced size vs the oracle, full size through its integer-lookup property."""
     tex = scenes.textures(scale=4)
