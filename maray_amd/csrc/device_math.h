@@ -27,6 +27,7 @@ MARAY_DEV double mr_sin(double a) { return maray_libm_sin(a); }
 MARAY_DEV double mr_stepsin(double a) { return maray_libm_step_sin(a); }
 MARAY_DEV double mr_stepsin_fast(double a, float *defer) { return maray_libm_step_sin_fast(a, defer); }
 MARAY_DEV double mr_stepsin_bounded(double a) { return maray_libm_step_sin_bounded(a); }
+MARAY_DEV bool mr_stepsin_bounded_b(double a) { return maray_libm_step_sin_bounded(a) != 0.0; }
 MARAY_DEV double mr_sin_bounded(double a) { return maray_libm_sin_bounded(a); }
 MARAY_DEV double mr_exp(double a) { return maray_libm_exp(a); }
 MARAY_DEV double mr_ln(double a) { return maray_libm_log(a); }

@@ -20,7 +20,9 @@
 #include <hip/hiprtc.h>
 
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -45,65 +47,136 @@ std::string lit(double v)
     return buf;
 }
 
+// Values whose every possible result is exactly +0.0 or 1.0 ("booleans": Step, Step(Sin), and
+// Mul / Min / Max / `1 + Neg(.)` of booleans) are carried as C++ `bool`s, i.e. wave lane masks that
+// the compiler combines with scalar s_and / s_or / s_andn2 instead of v_mul_f64 / v_min_f64 /
+// v_max_f64 + v_cndmask.  Exact, because on {+0.0, 1.0}: a*b = min(a,b) = a AND b, max(a,b) = a OR b,
+// 1 + (-a) = NOT a (1 + -1 = +0, 1 + -0 = 1) — all results are again +0.0 or 1.0, never -0.0.
+// About half of chess.maray's ops are of this kind.  The f64 value is materialised
+// (b ? 1.0 : 0.0) only where a non-boolean op consumes it.
 struct Emitter {
+    enum Kind { DBL, BOOL, NEGBOOL };   // NEGBOOL: value is -(b) in {-0.0, -1.0}, b = the named bool
+    struct Val {
+        Kind kind = DBL;
+        std::string d;   // name / literal of the double, empty until materialised
+        std::string b;   // name / literal of the bool (BOOL, NEGBOOL)
+    };
     const maray_program &P;
     std::string out;
+    std::vector<Val> vals;   // one per op of the current section
+    std::string yv_name = "yv";
     explicit Emitter(const maray_program &p) : P(p) {}
 
     void section(const uint64_t *ops, uint32_t n, uint32_t n_slots, bool pixel, const char *prefix)
     {
-        std::vector<std::string> slot(n_slots);
-        std::string acc;
-        char name[32];
-        auto ref = [&](uint32_t r) -> std::string {
+        vals.assign(n, Val());
+        std::vector<int> slot(n_slots, -1);
+        int acc = -1;
+        char name[48];
+        Val tmp_const[2];
+
+        // operand -> Val* (constants get a temporary)
+        auto ref = [&](uint32_t r, int which) -> Val * {
             const uint32_t kind = MARAY_REF_KIND(r), idx = MARAY_REF_INDEX(r);
+            Val &t = tmp_const[which];
+            t = Val();
             switch (kind) {
-            case MARAY_K_SLOT: return slot[idx];
-            case MARAY_K_CONST: return lit(P.consts[idx]);
-            case MARAY_K_YVAL: return "yv[" + std::to_string(idx) + "]";
-            default: return idx == MARAY_SPEC_X ? "X" : (idx == MARAY_SPEC_Y ? "Y" : acc);
+            case MARAY_K_SLOT: return &vals[slot[idx]];
+            case MARAY_K_CONST: {
+                const double c = P.consts[idx];
+                t.d = lit(c);
+                uint64_t bits; memcpy(&bits, &c, 8);
+                if (bits == 0x3ff0000000000000ull) { t.kind = BOOL; t.b = "true"; }
+                else if (bits == 0) { t.kind = BOOL; t.b = "false"; }
+                return &t;
+            }
+            case MARAY_K_YVAL: t.d = yv_name + "[" + std::to_string(idx) + "]"; return &t;
+            default:
+                if (idx == MARAY_SPEC_ACC) return &vals[acc];
+                t.d = idx == MARAY_SPEC_X ? "X" : "Y";
+                return &t;
             }
         };
+        // the double form of a value, materialising it once if needed
+        auto dbl = [&](Val *v, const char *hint, uint32_t i, int which) -> std::string {
+            if (!v->d.empty()) return v->d;
+            snprintf(name, sizeof name, "%s%u_%c", hint, i, which ? 'b' : 'a');
+            out += "    const double ";
+            out += name;
+            out += v->kind == BOOL ? " = " + v->b + " ? 1.0 : 0.0;\n" : " = " + v->b + " ? -1.0 : -0.0;\n";
+            v->d = name;
+            return v->d;
+        };
+
         for (uint32_t i = 0; i < n; i++) {
             const uint64_t ins = ops[i];
             const uint32_t op = MARAY_INS_OP(ins), aux = MARAY_INS_AUX(ins), dst = MARAY_INS_DST(ins);
             if (op == MARAY_OP_NOP) continue;
-            const std::string a = (op != MARAY_OP_TEXDIM) ? ref(MARAY_INS_A(ins)) : "";
+            Val *va = (op != MARAY_OP_TEXDIM) ? ref(MARAY_INS_A(ins), 0) : nullptr;
             if (op == MARAY_OP_OUT) {
+                const std::string a = dbl(va, "m", i, 0);
                 out += pixel ? "    o" + std::to_string(aux) + " = " + a + ";\n"
                              : "    yout[" + std::to_string(aux) + "] = " + a + ";\n";
                 continue;
             }
-            const std::string b = (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) ? ref(MARAY_INS_B(ins)) : "";
+            Val *vb = (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) ? ref(MARAY_INS_B(ins), 1) : nullptr;
             snprintf(name, sizeof name, "%s%u", prefix, i);
-            std::string e;
+            const std::string self = name;
+            Val r;
+            std::string e;      // double expression
+            std::string be;     // bool expression
+            const bool both_bool = va && vb && va->kind == BOOL && vb->kind == BOOL;
             switch (op) {
-            case MARAY_OP_MOV: e = a; break;
-            case MARAY_OP_NEG: e = "mr_neg(" + a + ")"; break;
-            case MARAY_OP_ABS: e = "mr_abs(" + a + ")"; break;
-            case MARAY_OP_RECIP: e = "mr_recip(" + a + ")"; break;
-            case MARAY_OP_SQRT: e = "mr_sqrt(" + a + ")"; break;
-            case MARAY_OP_STEP: e = "mr_step(" + a + ")"; break;
-            case MARAY_OP_SIN: e = (aux & MARAY_AUX_SIN_BOUNDED) ? "mr_sin_bounded(" + a + ")" : "mr_sin(" + a + ")"; break;
-            case MARAY_OP_STEPSIN:
-                e = (aux & MARAY_AUX_SIN_BOUNDED) ? "mr_stepsin_bounded(" + a + ")"
-                    : pixel ? "mr_stepsin_fast(" + a + ", &mr_defer)" : "mr_stepsin(" + a + ")";
+            case MARAY_OP_MOV: r = *va; break;
+            case MARAY_OP_NEG:
+                if (va->kind == BOOL) { r.kind = NEGBOOL; r.b = va->b; }
+                else e = "mr_neg(" + dbl(va, "m", i, 0) + ")";
                 break;
-            case MARAY_OP_EXP: e = "mr_exp(" + a + ")"; break;
-            case MARAY_OP_LN: e = "mr_ln(" + a + ")"; break;
-            case MARAY_OP_ADD: e = a + " + " + b; break;
-            case MARAY_OP_MUL: e = a + " * " + b; break;
-            case MARAY_OP_MAX: e = "mr_max(" + a + ", " + b + ")"; break;
-            case MARAY_OP_MIN: e = "mr_min(" + a + ", " + b + ")"; break;
-            case MARAY_OP_APP: e = "mr_app(tex, " + std::to_string(aux) + "u, " + a + ", " + b + ")"; break;
+            case MARAY_OP_STEP: be = "(" + dbl(va, "m", i, 0) + " >= 0.0)"; break;
+            case MARAY_OP_STEPSIN:
+                if (aux & MARAY_AUX_SIN_BOUNDED) be = "mr_stepsin_bounded_b(" + dbl(va, "m", i, 0) + ")";
+                else e = pixel ? "mr_stepsin_fast(" + dbl(va, "m", i, 0) + ", &mr_defer)" : "mr_stepsin(" + dbl(va, "m", i, 0) + ")";
+                break;
+            case MARAY_OP_ADD:
+                // 1.0 + (-(b)) = NOT b
+                if (va->kind == BOOL && va->b == "true" && vb->kind == NEGBOOL) be = "!" + vb->b;
+                else if (vb->kind == BOOL && vb->b == "true" && va->kind == NEGBOOL) be = "!" + va->b;
+                else e = dbl(va, "m", i, 0) + " + " + dbl(vb, "m", i, 1);
+                break;
+            case MARAY_OP_MUL:
+                if (both_bool) be = "(" + va->b + " & " + vb->b + ")";
+                else e = dbl(va, "m", i, 0) + " * " + dbl(vb, "m", i, 1);
+                break;
+            case MARAY_OP_MIN:
+                if (both_bool) be = "(" + va->b + " & " + vb->b + ")";
+                else e = "mr_min(" + dbl(va, "m", i, 0) + ", " + dbl(vb, "m", i, 1) + ")";
+                break;
+            case MARAY_OP_MAX:
+                if (both_bool) be = "(" + va->b + " | " + vb->b + ")";
+                else e = "mr_max(" + dbl(va, "m", i, 0) + ", " + dbl(vb, "m", i, 1) + ")";
+                break;
+            case MARAY_OP_ABS: e = "mr_abs(" + dbl(va, "m", i, 0) + ")"; break;
+            case MARAY_OP_RECIP: e = "mr_recip(" + dbl(va, "m", i, 0) + ")"; break;
+            case MARAY_OP_SQRT: e = "mr_sqrt(" + dbl(va, "m", i, 0) + ")"; break;
+            case MARAY_OP_SIN:
+                e = (aux & MARAY_AUX_SIN_BOUNDED) ? "mr_sin_bounded(" + dbl(va, "m", i, 0) + ")" : "mr_sin(" + dbl(va, "m", i, 0) + ")";
+                break;
+            case MARAY_OP_EXP: e = "mr_exp(" + dbl(va, "m", i, 0) + ")"; break;
+            case MARAY_OP_LN: e = "mr_ln(" + dbl(va, "m", i, 0) + ")"; break;
+            case MARAY_OP_APP: e = "mr_app(tex, " + std::to_string(aux) + "u, " + dbl(va, "m", i, 0) + ", " + dbl(vb, "m", i, 1) + ")"; break;
             case MARAY_OP_TEXDIM: e = "mr_texdim(tex, " + std::to_string(aux) + "u)"; break;
             default: throw Error{MARAY_E_ARG, "invalid opcode"};
             }
-            out += "    const double ";
-            out += name;
-            out += " = " + e + ";\n";
-            acc = name;
-            if (dst != MARAY_DST_NONE) slot[dst] = name;
+            if (!be.empty()) {
+                out += "    const bool b" + self + " = " + be + ";\n";
+                r.kind = BOOL; r.b = "b" + self;
+            } else if (!e.empty()) {
+                out += "    const double " + self + " = " + e + ";\n";
+                r.kind = DBL; r.d = self;
+            }
+            vals[i] = r;
+            acc = (int)i;
+            if (dst != MARAY_DST_NONE) slot[dst] = (int)i;
         }
     }
 };
@@ -144,19 +217,31 @@ std::string jit_source(const maray_program &P)
     std::string &s = E.out;
     s += "// generated by libmaray_hip (jit_backend.cpp) from a v" + std::to_string(P.version) + " tape: PIXEL section, " +
          std::to_string(P.n_pix_ops) + " ops\n";
+    // y values of the block's row: staged in LDS (broadcast ds_read_b128 into VGPRs) when they fit;
+    // as scalar loads they would park in SGPRs and spill through v_writelane / v_readlane.
+    // tuning knobs (environment): MARAY_JIT_YLDS=0/1, MARAY_JIT_WAVES=<min waves per SIMD for __launch_bounds__>
+    const char *env_ylds = getenv("MARAY_JIT_YLDS");
+    const char *env_waves = getenv("MARAY_JIT_WAVES");
+    const int min_waves = env_waves ? atoi(env_waves) : 4;   // chess @4096^2: 4 -> 3.54 ms, 0 -> 3.95 ms, 6 -> 4.56 ms
+    const bool y_lds = P.n_yvals > 0 && P.n_yvals <= 4096 && !(env_ylds && env_ylds[0] == '0');
+    if (y_lds) E.yv_name = "mr_ylds";
+    if (y_lds) s += "__shared__ double mr_ylds[" + std::to_string(P.n_yvals) + "];\n";
     s += "__shared__ unsigned mr_slow_tile;\n"
          "__device__ inline double mr_defer_sin(double) { mr_slow_tile = 1u; return 0.0; }\n"
          "#define MR_SIN_HUGE(x) mr_defer_sin(x)   // plain Sin ops: flag the tile from the (rare) branch\n"
          "#include \"device_math.h\"\n"
          "typedef const __attribute__((address_space(4))) double *mr_kptr;\n\n";
-    s += "extern \"C\" __global__ void __launch_bounds__(256) maray_jit_pixels(unsigned char *__restrict__ rgb8, double *__restrict__ rgb64,\n"
+    s += "extern \"C\" __global__ void __launch_bounds__(256" + (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string()) +
+         ") maray_jit_pixels(unsigned char *__restrict__ rgb8, double *__restrict__ rgb64,\n"
          "                                                                    const double *__restrict__ yvals, const MarayTex *__restrict__ tex,\n"
          "                                                                    unsigned *__restrict__ tile_flags,\n"
          "                                                                    unsigned w, unsigned y0, unsigned n_yvals)\n{\n"
          "    const unsigned x = blockIdx.x * 256u + threadIdx.x;\n"
          "    const unsigned r = blockIdx.y;\n"
-         "    if (threadIdx.x == 0) mr_slow_tile = 0u;\n"
-         "    __syncthreads();\n"
+         "    if (threadIdx.x == 0) mr_slow_tile = 0u;\n";
+    if (y_lds)
+        s += "    for (unsigned i = threadIdx.x; i < " + std::to_string(P.n_yvals) + "u; i += 256u) mr_ylds[i] = yvals[(size_t)r * n_yvals + i];\n";
+    s += "    __syncthreads();\n"
          "    const double X = (double)x, Y = (double)(y0 + r);\n"
          "    mr_kptr yv = (mr_kptr)(yvals + (size_t)r * n_yvals);\n"
          "    double o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"

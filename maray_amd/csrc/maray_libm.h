@@ -309,8 +309,7 @@ MR_FN double maray_libm_step_sin_bounded(double x)
     // bit 31 of s = sign of __sin(x): sign(a) in the sine quadrants, flipped in quadrants 2 and 3
     unsigned s = (n & 1u) ? 0u : (unsigned)(mr_bits(a) >> 32);
     s ^= n << 30;
-    const unsigned hi = ~(unsigned)((int)s >> 31) & 0x3ff00000u;      // 1.0 or 0.0
-    return mr_from_bits((unsigned long long)hi << 32);
+    return (int)s >= 0 ? 1.0 : 0.0;
 }
 
 // sin(x) under the same precondition: maray_libm_sin without its huge tail.

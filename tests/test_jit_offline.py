@@ -37,4 +37,5 @@ def test_chess_uses_the_pure_bounded_step_sin(chess_bytes):
     assert L.maray_jit_source(C.byref(tape.program), C.byref(src)) == 0
     text = C.string_at(src).decode()
     L.maray_free(src)
-    assert text.count('mr_stepsin_bounded(') == 256 and 'mr_stepsin_fast(' not in text
+    assert text.count('mr_stepsin_bounded_b(') == 256 and 'mr_stepsin_fast(' not in text
+    assert text.count('const bool ') > 3000          # half of chess is boolean algebra on lane masks
