@@ -86,7 +86,8 @@ typedef struct maray_lower_opts {
     uint32_t plain_cse;    /* 1 = hash-cons without commutative operand canonicalisation (reproduces the
                               op census of SURVEY.md §8(d)); 0 = canonicalise a+b/b+a etc. (default) */
     uint32_t no_fuse;      /* 1 = keep Step(Sin(a)) as two ops; 0 = fuse into MARAY_OP_STEPSIN (default) */
-    uint32_t reserved[5];
+    uint32_t no_skips;     /* 1 = do not emit SKIPZ / SKIPNZ wave-level short circuits; 0 = emit them (default) */
+    uint32_t reserved[4];
 } maray_lower_opts;
 
 typedef struct maray_tape_info {
@@ -97,6 +98,8 @@ typedef struct maray_tape_info {
     uint32_t folded_ops;       /* constant ops folded on the host */
     uint32_t dag_nodes;        /* unique DAG nodes including leaves */
     uint32_t acc_operands;     /* operand reads served by ACC */
+    uint32_t skip_ops;         /* SKIPZ / SKIPNZ ops in the PIXEL section */
+    uint32_t bool_ops;         /* PIXEL ops whose value is provably +0.0 or 1.0 */
     uint32_t sin_ops, sin_bounded;   /* Sin/StepSin ops, and how many have a proven-bounded argument */
     uint32_t op_histogram[MARAY_OP_COUNT];   /* PIXEL section */
 } maray_tape_info;

@@ -19,7 +19,7 @@
  * One op = one 64-bit little-endian word:
  *
  *   bits  0..6   opcode   (MARAY_OP_*)
- *   bits  7..19  aux      (OUT: output index; APP/TEXDIM: function id;
+ *   bits  7..19  aux      (OUT: output index; APP/TEXDIM: function id; SKIPZ/SKIPNZ: op count;
  *                         SIN/STEPSIN: bit 0 = MARAY_AUX_SIN_BOUNDED)
  *   bits 20..31  dst      (value slot written, or MARAY_DST_NONE)
  *   bits 32..47  a        (operand reference)
@@ -62,7 +62,16 @@ enum {
     MARAY_OP_TEXDIM = 15, /* App with id % 5 in {3,4}: image width / height (src/textures.rs:40-50), aux = id */
     MARAY_OP_OUT = 16,    /* output[aux] = a */
     MARAY_OP_STEPSIN = 17, /* Step(Sin(a)) fused: :644-648; only the sign of glibc's sin is computed */
-    MARAY_OP_COUNT = 18
+    /* Wave-level short circuit of boolean algebra (values that are exactly +0.0 or 1.0):
+     * SKIPZ  a, n: if a == 0.0 on every lane of the wavefront, the result of the AND (Mul / Min)
+     *              that ends the next n ops is +0.0 whatever its other operand is: write +0.0 to dst
+     *              (if any) and ACC, and skip those n ops.  Otherwise no effect (ACC unchanged).
+     * SKIPNZ a, n: same for an OR (Max) when a == 1.0 on every lane: the result is 1.0.
+     * n = aux.  The skipped ops define no value that is read after them, and contain no OUT.
+     * An evaluator may ignore both ops (never skip): results are identical. */
+    MARAY_OP_SKIPZ = 18,
+    MARAY_OP_SKIPNZ = 19,
+    MARAY_OP_COUNT = 20
 };
 
 /* SIN / STEPSIN aux bit 0: the lowering proved by interval arithmetic that the

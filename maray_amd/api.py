@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-OP_COUNT = 18
+OP_COUNT = 20
 BACKEND_TAPE, BACKEND_TAPE_SMEM, BACKEND_JIT, BACKEND_AUTO = 0, 1, 2, 3
 REPORT_NONE, REPORT_ROW, REPORT_DURATION_MS = 0, 1, 2
 
@@ -31,7 +31,7 @@ class TapeInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in
                 ('n_consts', 'n_row_ops', 'n_row_slots', 'n_yvals', 'n_pix_ops', 'n_pix_slots', 'n_app', 'alg_ops',
                  'alg_ops_xy', 'alg_ops_x', 'alg_ops_y', 'alg_ops_uniform', 'folded_ops', 'dag_nodes',
-                 'acc_operands', 'sin_ops', 'sin_bounded')] + [('op_histogram', C.c_uint32 * OP_COUNT)]
+                 'acc_operands', 'skip_ops', 'bool_ops', 'sin_ops', 'sin_bounded')] + [('op_histogram', C.c_uint32 * OP_COUNT)]
 
 
 class Texture(C.Structure):
@@ -39,7 +39,7 @@ class Texture(C.Structure):
 
 
 class LowerOpts(C.Structure):
-    _fields_ = [('hoist_rows', C.c_uint32), ('plain_cse', C.c_uint32), ('no_fuse', C.c_uint32), ('reserved', C.c_uint32 * 5)]
+    _fields_ = [('hoist_rows', C.c_uint32), ('plain_cse', C.c_uint32), ('no_fuse', C.c_uint32), ('no_skips', C.c_uint32), ('reserved', C.c_uint32 * 4)]
 
 
 class CtxOpts(C.Structure):
@@ -200,18 +200,19 @@ class Scene:
     def rescale(self, sx, sy):
         _check(lib().maray_scene_rescale(self._h, sx, sy))
 
-    def lower(self, hoist_rows=True, plain_cse=False, fuse=True):
-        return Tape(self, hoist_rows, plain_cse, fuse)
+    def lower(self, hoist_rows=True, plain_cse=False, fuse=True, skips=True):
+        return Tape(self, hoist_rows, plain_cse, fuse, skips)
 
 
 class Tape:
     """Lowered program (include/maray_tape.h)."""
 
-    def __init__(self, scene, hoist_rows=True, plain_cse=False, fuse=True):
+    def __init__(self, scene, hoist_rows=True, plain_cse=False, fuse=True, skips=True):
         o = LowerOpts()
         o.hoist_rows = 1 if hoist_rows else 0
         o.plain_cse = 1 if plain_cse else 0
         o.no_fuse = 0 if fuse else 1
+        o.no_skips = 0 if skips else 1
         h = C.c_void_p()
         _check(lib().maray_lower(scene._h, C.byref(o), C.byref(h)))
         self._h = h

@@ -88,12 +88,23 @@ void validate_program(const maray_program &p)
     auto check = [&](const uint64_t *ops, uint32_t n, uint32_t n_slots, bool pixel) {
         std::vector<uint8_t> written(n_slots, 0);
         bool have_acc = false;
+        struct Region { uint32_t end; std::vector<uint8_t> before; uint32_t dst; };
+        std::vector<Region> regions;               // open SKIPZ / SKIPNZ regions, innermost last
         for (uint32_t i = 0; i < n; i++) {
             const uint64_t ins = ops[i];
             const uint32_t op = MARAY_INS_OP(ins), aux = MARAY_INS_AUX(ins), dst = MARAY_INS_DST(ins);
             if (op >= MARAY_OP_COUNT) throw Error{MARAY_E_ARG, "invalid opcode at op " + std::to_string(i)};
-            if (op == MARAY_OP_NOP) continue;
-            const int arity = (op == MARAY_OP_TEXDIM) ? 0 : (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) ? 2 : 1;   // STEPSIN, OUT, MOV and the unary ops read `a` only
+            auto close_regions = [&]() {
+                // values written only inside a skipped region do not exist on the skip path
+                while (!regions.empty() && regions.back().end == i) {
+                    written = regions.back().before;
+                    if (regions.back().dst != MARAY_DST_NONE) written[regions.back().dst] = 1;
+                    if (dst != regions.back().dst) throw Error{MARAY_E_ARG, "skip region does not end in its own destination at op " + std::to_string(i)};
+                    regions.pop_back();
+                }
+            };
+            if (op == MARAY_OP_NOP) { close_regions(); continue; }
+            const int arity = (op == MARAY_OP_TEXDIM) ? 0 : (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) ? 2 : 1;   // STEPSIN, OUT, MOV, SKIP* and the unary ops read `a` only
             const uint32_t refs[2] = {MARAY_INS_A(ins), MARAY_INS_B(ins)};
             for (int k = 0; k < arity; k++) {
                 const uint32_t kind = MARAY_REF_KIND(refs[k]), idx = MARAY_REF_INDEX(refs[k]);
@@ -108,6 +119,17 @@ void validate_program(const maray_program &p)
             }
             if (op == MARAY_OP_OUT) {
                 if (aux >= (pixel ? 3u : p.n_yvals)) throw Error{MARAY_E_ARG, "output index out of range at op " + std::to_string(i)};
+                if (!regions.empty()) throw Error{MARAY_E_ARG, "OUT inside a skip region at op " + std::to_string(i)};
+                continue;
+            }
+            if (op == MARAY_OP_SKIPZ || op == MARAY_OP_SKIPNZ) {
+                if (aux == 0 || (uint64_t)i + aux >= n) throw Error{MARAY_E_ARG, "skip count out of range at op " + std::to_string(i)};
+                if (!regions.empty() && i + aux > regions.back().end) throw Error{MARAY_E_ARG, "skip regions overlap at op " + std::to_string(i)};
+                if (dst != MARAY_DST_NONE && dst >= n_slots) throw Error{MARAY_E_ARG, "dst slot out of range at op " + std::to_string(i)};
+                const uint32_t last = MARAY_INS_OP(ops[i + aux]);
+                if (!(last == MARAY_OP_MUL || last == MARAY_OP_MIN || last == MARAY_OP_MAX))
+                    throw Error{MARAY_E_ARG, "skip region must end in Mul / Min / Max at op " + std::to_string(i)};
+                regions.push_back(Region{i + aux, written, dst});
                 continue;
             }
             if ((op == MARAY_OP_APP || op == MARAY_OP_TEXDIM) && aux >= p.n_app)
@@ -117,7 +139,9 @@ void validate_program(const maray_program &p)
                 written[dst] = 1;
             }
             have_acc = true;
+            close_regions();
         }
+        if (!regions.empty()) throw Error{MARAY_E_ARG, "unterminated skip region"};
     };
     check(p.row_ops, p.n_row_ops, p.n_row_slots, false);
     check(p.pix_ops, p.n_pix_ops, p.n_pix_slots, true);

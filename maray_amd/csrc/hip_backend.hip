@@ -108,6 +108,22 @@ __device__ __forceinline__ void run_tape(const KArgs &A, const uint64_t *tape_ld
         case MARAY_OP_MIN: { const double a = fetch(ra), b = fetch(rb); r = mr_min(a, b); break; }
         case MARAY_OP_APP: { const double a = fetch(ra), b = fetch(rb); r = mr_app(A.tex, aux, a, b); break; }
         case MARAY_OP_TEXDIM: r = mr_texdim(A.tex, aux); break;
+        case MARAY_OP_SKIPZ: case MARAY_OP_SKIPNZ: {
+            // wave-level short circuit of boolean algebra: every lane of this wavefront agrees that the
+            // AND (OR) ending `aux` ops further down is 0 (1) -> define its value and jump over the region
+            const double gv = fetch(ra);
+            const bool decided = (op == MARAY_OP_SKIPZ) ? (__builtin_amdgcn_ballot_w64(gv != 0.0) == 0ull)
+                                                        : (__builtin_amdgcn_ballot_w64(gv != 1.0) == 0ull);
+            if (decided) {
+                acc = (op == MARAY_OP_SKIPZ) ? 0.0 : 1.0;
+                if (dst != MARAY_DST_NONE) {
+                    if (dst < n_lds) slots[dst * BLOCK + tid] = acc;
+                    else spill_base[(size_t)(dst - n_lds) * spill_stride] = acc;
+                }
+                pc += aux;
+            }
+            continue;
+        }
         case MARAY_OP_OUT: {
             const double v = fetch(ra);
             if (ROW) yout[aux] = v;

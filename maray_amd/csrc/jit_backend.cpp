@@ -108,11 +108,27 @@ struct Emitter {
             return v->d;
         };
 
+        struct Open { uint32_t end; bool as_bool; bool nz; };
+        std::vector<Open> open;     // SKIPZ / SKIPNZ regions being emitted, innermost last
         for (uint32_t i = 0; i < n; i++) {
             const uint64_t ins = ops[i];
             const uint32_t op = MARAY_INS_OP(ins), aux = MARAY_INS_AUX(ins), dst = MARAY_INS_DST(ins);
             if (op == MARAY_OP_NOP) continue;
             Val *va = (op != MARAY_OP_TEXDIM) ? ref(MARAY_INS_A(ins), 0) : nullptr;
+            if (op == MARAY_OP_SKIPZ || op == MARAY_OP_SKIPNZ) {
+                // if (some lane still needs it) { region } else result = 0 / 1;  -- a scalar branch on the ballot
+                const bool nz = op == MARAY_OP_SKIPNZ;
+                const uint32_t end = i + aux;
+                snprintf(name, sizeof name, "%s%u", prefix, end);
+                const bool as_bool = va->kind == BOOL;
+                std::string cond;
+                if (as_bool) cond = nz ? "!" + va->b : va->b;
+                else cond = "(" + dbl(va, "m", i, 0) + (nz ? " != 1.0)" : " != 0.0)");
+                out += as_bool ? "    bool b" + std::string(name) + ";\n" : "    double " + std::string(name) + ";\n";
+                out += "    if (__builtin_amdgcn_ballot_w64(" + cond + ") != 0ull) {\n";
+                open.push_back(Open{end, as_bool, nz});
+                continue;
+            }
             if (op == MARAY_OP_OUT) {
                 const std::string a = dbl(va, "m", i, 0);
                 out += pixel ? "    o" + std::to_string(aux) + " = " + a + ";\n"
@@ -167,7 +183,25 @@ struct Emitter {
             case MARAY_OP_TEXDIM: e = "mr_texdim(tex, " + std::to_string(aux) + "u)"; break;
             default: throw Error{MARAY_E_ARG, "invalid opcode"};
             }
-            if (!be.empty()) {
+            const bool closes = !open.empty() && open.back().end == i;
+            if (closes) {
+                // the AND / OR that ends a region: assign the variable declared before the `if`
+                const Open o = open.back();
+                open.pop_back();
+                if (o.as_bool && !be.empty()) {
+                    out += "    b" + self + " = " + be + ";\n    } else b" + self + (o.nz ? " = true;\n" : " = false;\n");
+                    r.kind = BOOL; r.b = "b" + self;
+                } else if (o.as_bool) {
+                    // guard was boolean but the result is not typed so: keep the double form
+                    out += "    b" + self + " = (" + e + ") != 0.0;\n    } else b" + self + (o.nz ? " = true;\n" : " = false;\n");
+                    r.kind = BOOL; r.b = "b" + self;
+                } else {
+                    const std::string ee = !e.empty() ? e : "(" + be + " ? 1.0 : 0.0)";
+                    out += "    " + self + " = " + ee + ";\n    } else " + self + (o.nz ? " = 1.0;\n" : " = 0.0;\n");
+                    r.kind = DBL; r.d = self;
+                }
+                if (!open.empty() && open.back().end == i) throw Error{MARAY_E_ARG, "two skip regions end at one op"};
+            } else if (!be.empty()) {
                 out += "    const bool b" + self + " = " + be + ";\n";
                 r.kind = BOOL; r.b = "b" + self;
             } else if (!e.empty()) {

@@ -280,20 +280,35 @@ std::vector<Ival> intervals(const Dag &g)
 }
 
 // ---- section scheduling + encoding --------------------------------------------------
+// One scheduled tape op.
+struct SItem {
+    int32_t node;          // NODE: the computing node; OUT: the node read; SKIP: the guard
+    int32_t out = -1;      // >= 0: OUT op of this output index
+    int32_t target = -1;   // >= 0: SKIPZ / SKIPNZ op guarding the region that ends with node `target`
+    uint8_t nz = 0;        // SKIP: 0 = SKIPZ (AND), 1 = SKIPNZ (OR)
+};
+
 struct Section {
-    std::vector<int32_t> order;                 // computing nodes in schedule order
+    std::vector<SItem> sched;                   // NODE and SKIP items in schedule order
     std::vector<std::pair<int32_t, uint32_t>> outs;   // (node, output index)
     std::vector<uint64_t> ops;
     uint32_t n_slots = 0;
     uint32_t acc_operands = 0;
+    uint32_t n_skips = 0;
 };
+
+constexpr size_t MIN_REGION = 6;                // smallest exclusive cone worth a SKIP op
+constexpr size_t MAX_REGION = 0x1FFF;           // aux field
 
 struct Lowerer {
     const Dag &g;
     std::vector<uint8_t> sin_bounded;           // per node: Sin/StepSin argument proven inside reduce_sincos range
+    std::vector<uint8_t> isbool;                // per node: value is provably +0.0 or 1.0
+    bool regions = true;
     std::vector<uint8_t> in_section;            // node belongs to the section being built
     std::vector<int32_t> need;                  // Sethi-Ullman label
     std::vector<uint8_t> visited;
+    std::vector<std::vector<int32_t>> users;    // consumers inside the section (an OUT counts as user -1)
     std::unordered_map<uint64_t, uint32_t> const_index;
     std::vector<double> consts;
     std::vector<int32_t> yval_of;               // node -> y value index or -1
@@ -324,68 +339,149 @@ struct Lowerer {
         return r;
     }
 
-    void visit(int32_t i, Section &sec) {
-        if (visited[i] || !in_section[i]) return;
-        visited[i] = 1;
+    void prepare(const Section &sec) {
+        const size_t N = g.n.size();
+        need.assign(N, -1);
+        visited.assign(N, 0);
+        users.assign(N, {});
+        for (size_t i = 0; i < N; i++) {
+            if (!in_section[i]) continue;
+            for (int32_t c : {g.n[i].a, g.n[i].b}) if (c >= 0 && in_section[c]) users[c].push_back((int32_t)i);
+        }
+        for (auto &o : sec.outs) if (in_section[o.first]) users[o.first].push_back(-1);
+    }
+
+    // Unvisited section nodes reachable from `root`, ascending (= topological) order.
+    std::vector<int32_t> reach(int32_t root) {
+        std::vector<int32_t> r, st{root};
+        std::unordered_set<int32_t> seen;
+        while (!st.empty()) {
+            int32_t v = st.back(); st.pop_back();
+            if (v < 0 || !in_section[v] || visited[v] || !seen.insert(v).second) continue;
+            r.push_back(v);
+            st.push_back(g.n[v].a); st.push_back(g.n[v].b);
+        }
+        std::sort(r.begin(), r.end());
+        return r;
+    }
+
+    // The exclusive cone of `body` with respect to its consumer `n`: the nodes of reach(body) that
+    // are used by nothing but n or other nodes of the cone, i.e. that become dead when n's value is
+    // known without them.
+    std::unordered_set<int32_t> exclusive_cone(int32_t body, int32_t n, const std::vector<int32_t> &r) {
+        std::unordered_set<int32_t> in_r(r.begin(), r.end()), cone;
+        for (auto it = r.rbegin(); it != r.rend(); ++it) {      // consumers before producers
+            const int32_t v = *it;
+            bool excl = !users[v].empty();
+            for (int32_t u : users[v]) {
+                if (u == n && v == body) continue;
+                if (u < 0 || !cone.count(u)) { excl = false; break; }
+            }
+            if (excl) cone.insert(v);
+        }
+        (void)in_r;
+        return cone;
+    }
+
+    int region_kind(int32_t i) const {          // 1: AND (Mul/Min of booleans), 2: OR (Max of booleans)
         const DNode &d = g.n[i];
+        if (!isbool[i] || d.a < 0 || d.b < 0 || d.a == d.b || !isbool[d.a] || !isbool[d.b]) return 0;
+        if (d.op == MARAY_OP_MUL || d.op == MARAY_OP_MIN) return 1;
+        if (d.op == MARAY_OP_MAX) return 2;
+        return 0;
+    }
+
+    void visit(int32_t i, Section &sec) {
+        if (i < 0 || visited[i] || !in_section[i]) return;
+        const DNode &d = g.n[i];
+        const int kind = regions ? region_kind(i) : 0;
+        if (kind) {
+            // orientation: the operand with the smaller exclusive cone guards the other one
+            size_t best = 0;
+            int32_t guard = -1, body = -1;
+            for (int o = 0; o < 2; o++) {
+                const int32_t bq = o ? d.a : d.b, gq = o ? d.b : d.a;
+                if (!in_section[bq] || visited[bq] || g.n[bq].op >= D_CONST) continue;
+                const std::vector<int32_t> r = reach(bq);
+                const size_t sz = exclusive_cone(bq, i, r).size();
+                if (sz >= MIN_REGION && sz > best) { best = sz; guard = gq; body = bq; }
+            }
+            if (guard >= 0 && g.n[guard].op != D_CONST) {
+                visited[i] = 1;
+                visit(guard, sec);
+                if (!visited[body]) {
+                    const std::vector<int32_t> r = reach(body);
+                    const std::unordered_set<int32_t> cone = exclusive_cone(body, i, r);
+                    if (cone.size() >= MIN_REGION && cone.count(body)) {
+                        for (int32_t v : r) if (!cone.count(v)) visit(v, sec);   // shared nodes: computed unconditionally
+                        const size_t mark = sec.sched.size();
+                        SItem sk; sk.node = guard; sk.target = i; sk.nz = kind == 2;
+                        sec.sched.push_back(sk);
+                        visit(body, sec);
+                        SItem self; self.node = i;
+                        sec.sched.push_back(self);
+                        if (sec.sched.size() - mark - 1 > MAX_REGION) sec.sched.erase(sec.sched.begin() + (long)mark);
+                        return;
+                    }
+                }
+                visit(body, sec);
+                SItem self; self.node = i;
+                sec.sched.push_back(self);
+                return;
+            }
+        }
+        visited[i] = 1;
         int32_t c0 = d.a, c1 = d.b;
         bool h0 = c0 >= 0 && in_section[c0], h1 = c1 >= 0 && in_section[c1];
         if (h0 && h1 && su(c1) > su(c0)) std::swap(c0, c1);   // heavier sub-tree first
         if (c0 >= 0) visit(c0, sec);
         if (c1 >= 0) visit(c1, sec);
-        sec.order.push_back(i);
+        SItem self; self.node = i;
+        sec.sched.push_back(self);
     }
 
     void build(Section &sec, bool pixel) {
-        size_t N = g.n.size();
-        need.assign(N, -1);
-        visited.assign(N, 0);
+        const size_t N = g.n.size();
+        prepare(sec);
         for (auto &o : sec.outs) if (in_section[o.first]) visit(o.first, sec);
 
-        // Item list: each computing node, followed immediately by the OUT ops that read it.
-        struct Item { int32_t node; int32_t out; };   // out >= 0: OUT op of output `out` reading `node`
-        std::vector<Item> items;
-        std::unordered_map<int32_t, std::vector<uint32_t>> outs_of;
-        for (auto &o : sec.outs) outs_of[o.first].push_back(o.second);
-        std::vector<int32_t> item_pos(N, -1);          // position of the item that LAST leaves node in ACC
-        for (int32_t nd : sec.order) {
-            items.push_back({nd, -1});
-            item_pos[nd] = (int32_t)items.size() - 1;
-            // OUT does not modify ACC, so consecutive OUTs of one node all read ACC
-        }
-        // insert OUTs: rebuild with OUTs right after their node
+        // Final item list: OUT ops go right after the node they read (never inside a skipped
+        // region: a node with an OUT is not exclusive to anything).
+        std::vector<SItem> items;
         {
-            std::vector<Item> with;
-            with.reserve(items.size() + sec.outs.size());
-            for (const Item &it : items) {
-                with.push_back(it);
+            std::unordered_map<int32_t, std::vector<uint32_t>> outs_of;
+            for (auto &o : sec.outs) outs_of[o.first].push_back(o.second);
+            items.reserve(sec.sched.size() + sec.outs.size());
+            for (const SItem &it : sec.sched) {
+                items.push_back(it);
+                if (it.target >= 0) continue;
                 auto f = outs_of.find(it.node);
-                if (f != outs_of.end()) for (uint32_t k : f->second) with.push_back({it.node, (int32_t)k});
+                if (f != outs_of.end()) for (uint32_t k : f->second) { SItem o; o.node = it.node; o.out = (int32_t)k; items.push_back(o); }
             }
-            for (auto &o : sec.outs) if (!in_section[o.first]) with.push_back({o.first, (int32_t)o.second});   // const / leaf / yval roots
-            items.swap(with);
+            for (auto &o : sec.outs) if (!in_section[o.first]) { SItem x; x.node = o.first; x.out = (int32_t)o.second; items.push_back(x); }
         }
-        // positions and last uses
-        std::vector<int32_t> last_use(N, -1), first_far_use(N, 0);
-        std::fill(item_pos.begin(), item_pos.end(), -1);
-        std::vector<int32_t> acc_pos(N, -1);   // item index after which ACC holds node (until the next computing item)
-        for (size_t j = 0; j < items.size(); j++) if (items[j].out < 0) item_pos[items[j].node] = (int32_t)j;
-        // ACC validity: ACC holds the result of the latest computing item; OUT items do not disturb it.
+        auto is_node = [](const SItem &it) { return it.out < 0 && it.target < 0; };
+        std::vector<int32_t> item_pos(N, -1);
+        for (size_t j = 0; j < items.size(); j++) if (is_node(items[j])) item_pos[items[j].node] = (int32_t)j;
+
+        // ACC holds the result of the latest computing item; OUT and SKIP items do not disturb it
+        // (a taken SKIP leaves its target's value in ACC, exactly what the target op would have left).
         std::vector<int32_t> acc_holder(items.size(), -1);
         {
             int32_t cur = -1;
             for (size_t j = 0; j < items.size(); j++) {
-                acc_holder[j] = cur;                   // node in ACC when item j executes
-                if (items[j].out < 0) cur = items[j].node;
+                acc_holder[j] = cur;
+                if (is_node(items[j])) cur = items[j].node;
             }
         }
+        std::vector<int32_t> last_use(N, -1), needs_slot(N, 0);
         auto note_use = [&](int32_t c, size_t j) {
             if (c < 0 || !in_section[c]) return;
             last_use[c] = (int32_t)j;
-            if (acc_holder[j] != c) first_far_use[c] = 1;   // some use cannot be served by ACC -> needs a slot
+            if (acc_holder[j] != c) needs_slot[c] = 1;   // some use cannot be served by ACC
         };
         for (size_t j = 0; j < items.size(); j++) {
-            if (items[j].out >= 0) note_use(items[j].node, j);
+            if (!is_node(items[j])) note_use(items[j].node, j);
             else { note_use(g.n[items[j].node].a, j); note_use(g.n[items[j].node].b, j); }
         }
 
@@ -425,11 +521,22 @@ struct Lowerer {
             throw Error{MARAY_E_INTERNAL, "operand outside its section"};
         };
         for (size_t j = 0; j < items.size(); j++) {
-            const Item &it = items[j];
+            const SItem &it = items[j];
             if (it.out >= 0) {
                 uint32_t a = opref(it.node, j);
                 release(it.node, j);
                 sec.ops.push_back(MARAY_INS(MARAY_OP_OUT, (uint32_t)it.out, MARAY_DST_NONE, a, 0));
+                continue;
+            }
+            if (it.target >= 0) {
+                // the region's result slot is reserved here so that both paths define it
+                const uint32_t a = opref(it.node, j);
+                release(it.node, j);
+                uint32_t dst = MARAY_DST_NONE;
+                if (needs_slot[it.target]) { dst = alloc(); slot[it.target] = (int32_t)dst; }
+                const uint32_t count = (uint32_t)(item_pos[it.target] - (int32_t)j);
+                sec.ops.push_back(MARAY_INS(it.nz ? MARAY_OP_SKIPNZ : MARAY_OP_SKIPZ, count, dst, a, 0));
+                sec.n_skips++;
                 continue;
             }
             const DNode &d = g.n[it.node];
@@ -438,7 +545,8 @@ struct Lowerer {
             release(d.a, j);
             if (d.b != d.a) release(d.b, j);
             uint32_t dst = MARAY_DST_NONE;
-            if (first_far_use[it.node]) { dst = alloc(); slot[it.node] = (int32_t)dst; }
+            if (slot[it.node] >= 0) dst = (uint32_t)slot[it.node];            // reserved by this region's SKIP op
+            else if (needs_slot[it.node]) { dst = alloc(); slot[it.node] = (int32_t)dst; }
             if (d.aux > 0x1FFFu) throw Error{MARAY_E_LIMIT, "App id above 8191"};
             uint32_t aux = d.aux;
             if ((d.op == MARAY_OP_SIN || d.op == MARAY_OP_STEPSIN) && sin_bounded[it.node]) aux |= MARAY_AUX_SIN_BOUNDED;
@@ -498,6 +606,20 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
     info.n_app = max_app;
 
     Lowerer L(g);
+    L.regions = opts.no_skips == 0;
+    L.isbool.assign(N, 0);
+    for (size_t i = 0; i < N; i++) {                  // values that are provably +0.0 or 1.0
+        const DNode &d = g.n[i];
+        auto is_one = [&](int32_t c) { return c >= 0 && g.n[c].op == D_CONST && bits_of(g.n[c].cval) == 0x3ff0000000000000ull; };
+        auto is_negbool = [&](int32_t c) { return c >= 0 && g.n[c].op == MARAY_OP_NEG && L.isbool[g.n[c].a]; };
+        switch (d.op) {
+        case D_CONST: L.isbool[i] = bits_of(d.cval) == 0 || bits_of(d.cval) == 0x3ff0000000000000ull; break;
+        case MARAY_OP_STEP: case MARAY_OP_STEPSIN: L.isbool[i] = 1; break;
+        case MARAY_OP_MUL: case MARAY_OP_MIN: case MARAY_OP_MAX: L.isbool[i] = L.isbool[d.a] && L.isbool[d.b]; break;
+        case MARAY_OP_ADD: L.isbool[i] = (is_one(d.a) && is_negbool(d.b)) || (is_one(d.b) && is_negbool(d.a)); break;   // 1 + -(b) = NOT b
+        default: break;
+        }
+    }
     {
         const std::vector<Ival> iv = intervals(g);
         L.sin_bounded.assign(N, 0);
@@ -527,15 +649,15 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         std::vector<uint8_t> is_pix0(N, 0);
         for (size_t i = 0; i < N; i++) if (reach[i] && is_op((int32_t)i) && !is_row[i]) is_pix0[i] = 1;
         Section dry;
+        for (int c = 0; c < 3; c++) dry.outs.push_back({roots[c], (uint32_t)c});
         L.in_section = is_pix0;
-        L.need.assign(N, -1);
-        L.visited.assign(N, 0);
+        L.prepare(dry);
         for (int c = 0; c < 3; c++) if (is_pix0[roots[c]]) L.visit(roots[c], dry);
         uint32_t k = 0;
         auto number = [&](int32_t c) {
             if (c >= 0 && frontier[c] && L.yval_of[c] < 0) { L.yval_of[c] = (int32_t)k; row.outs.push_back({c, k}); k++; }
         };
-        for (int32_t nd : dry.order) { number(g.n[nd].a); number(g.n[nd].b); }
+        for (const SItem &it : dry.sched) if (it.target < 0) { number(g.n[it.node].a); number(g.n[it.node].b); }
         for (int c = 0; c < 3; c++) number(roots[c]);
         for (size_t i = 0; i < N; i++) number((int32_t)i);
         info.n_yvals = k;
@@ -560,6 +682,8 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
     info.n_pix_ops = (uint32_t)t.pix_ops.size();
     info.n_pix_slots = pix.n_slots;
     info.acc_operands = pix.acc_operands;
+    info.skip_ops = pix.n_skips;
+    for (size_t i = 0; i < N; i++) if (is_pix[i] && L.isbool[i]) info.bool_ops++;
     for (uint64_t ins : t.pix_ops) info.op_histogram[MARAY_INS_OP(ins)]++;
 }
 

@@ -10,7 +10,7 @@ import math
 import numpy as np
 
 OP = dict(NOP=0, MOV=1, NEG=2, ABS=3, RECIP=4, SQRT=5, STEP=6, SIN=7, EXP=8, LN=9, ADD=10, MUL=11, MAX=12, MIN=13,
-          APP=14, TEXDIM=15, OUT=16, STEPSIN=17)
+          APP=14, TEXDIM=15, OUT=16, STEPSIN=17, SKIPZ=18, SKIPNZ=19)
 K_SLOT, K_CONST, K_YVAL, K_SPEC = 0, 1, 2, 3
 DST_NONE = 0xFFF
 
@@ -46,9 +46,10 @@ def _cast_u32(v):
     return np.minimum(v, 4294967295.0).astype(np.uint64)
 
 
-def run_section(ops, consts, n_slots, X, Y, yvals, textures, n_out):
+def run_section(ops, consts, n_slots, X, Y, yvals, textures, n_out, honor_skips=False):
     """Evaluate one section for a vector of items.  X, Y: float64 arrays (same
-    shape); yvals: array [..., n_yvals] broadcastable per item or None."""
+    shape); yvals: array [..., n_yvals] broadcastable per item or None.
+    honor_skips: take SKIPZ / SKIPNZ when the whole vector agrees (call per 64-item "wavefront")."""
     shape = np.shape(Y)
     slots = [None] * max(n_slots, 1)
     outs = [None] * n_out
@@ -62,9 +63,21 @@ def run_section(ops, consts, n_slots, X, Y, yvals, textures, n_out):
         return X if idx == 0 else (Y if idx == 1 else acc)
 
     with np.errstate(all='ignore'):
-        for ins in ops:
-            op, aux, dst, ra, rb = decode(ins)
+        pc = -1
+        n_ops = len(ops)
+        while pc + 1 < n_ops:
+            pc += 1
+            op, aux, dst, ra, rb = decode(ops[pc])
             if op == OP['NOP']: continue
+            if op in (OP['SKIPZ'], OP['SKIPNZ']):
+                if not honor_skips: continue                                   # an evaluator may ignore the skips
+                gv = fetch(ra)
+                want = 0.0 if op == OP['SKIPZ'] else 1.0
+                if np.all(gv == want):
+                    acc = np.full(shape, want)
+                    if dst != DST_NONE: slots[dst] = acc
+                    pc += aux
+                continue
             if op == OP['OUT']:
                 outs[aux] = fetch(ra); continue
             if op == OP['MOV']: r = fetch(ra)
@@ -98,6 +111,31 @@ def run_section(ops, consts, n_slots, X, Y, yvals, textures, n_out):
             if dst != DST_NONE:
                 slots[dst] = r
     return outs
+
+
+def render_rows_waves(tape, w, y0, y1, textures=None):
+    """Like render_rows, but wavefront by wavefront (64 consecutive x of one row; the ROW section in
+    groups of 64 rows) with SKIPZ / SKIPNZ honoured the way the device kernels do."""
+    consts, row_ops, pix_ops = tape.arrays()
+    info = tape.info
+    rows = y1 - y0
+    out = np.zeros((rows, w, 3))
+    yv_all = None
+    if info['n_yvals']:
+        yv_all = np.zeros((rows, info['n_yvals']))
+        for r0 in range(0, rows, 64):
+            ys = np.arange(y0 + r0, min(y1, y0 + r0 + 64), dtype=np.float64)
+            outs = run_section(row_ops, consts, info['n_row_slots'], None, ys, None, textures, info['n_yvals'], True)
+            yv_all[r0:r0 + len(ys)] = np.stack(outs, axis=-1)
+    for r in range(rows):
+        for x0 in range(0, w, 64):
+            X = np.arange(x0, x0 + 64, dtype=np.float64)        # lanes beyond w compute too, like on the device
+            Y = np.full(64, float(y0 + r))
+            yv = np.broadcast_to(yv_all[r][None, :], (64, info['n_yvals'])) if yv_all is not None else None
+            o = run_section(pix_ops, consts, info['n_pix_slots'], X, Y, yv, textures, 3, True)
+            n = min(64, w - x0)
+            out[r, x0:x0 + n] = np.stack(o, axis=-1)[:n]
+    return out
 
 
 def render_rows(tape, w, y0, y1, textures=None):

@@ -76,9 +76,10 @@ def test_chess_tape_census(chess_bytes):
     assert info['alg_ops'] == info['alg_ops_xy'] + info['alg_ops_x'] + info['alg_ops_y'] + info['alg_ops_uniform']
     fused = info['op_histogram'][tape_eval.OP['STEPSIN']]
     assert fused == 256                       # every Sin of chess feeds a Step (SURVEY.md finding 4)
-    assert info['n_pix_ops'] == info['alg_ops_xy'] + info['alg_ops_x'] + 3 - fused   # a fused op stands for two
+    assert info['n_pix_ops'] == info['alg_ops_xy'] + info['alg_ops_x'] + 3 - fused + info['skip_ops']   # a fused op stands for two
     assert info['n_row_ops'] == info['alg_ops_y'] + info['n_yvals']
-    assert info['n_pix_slots'] <= 32            # Sethi-Ullman order keeps few values live
+    assert M.Scene(chess_bytes).lower(skips=False).info['n_pix_slots'] <= 32   # Sethi-Ullman order keeps few values live
+    assert info['n_pix_slots'] <= 96            # hoisting shared nodes out of skip regions costs some
     assert info['op_histogram'][tape_eval.OP['SIN']] == 0
     unfused = M.Scene(chess_bytes).lower(fuse=False).info
     assert unfused['op_histogram'][tape_eval.OP['SIN']] == 256 and unfused['alg_ops'] == info['alg_ops']
@@ -92,6 +93,33 @@ def test_chess_tape_census(chess_bytes):
 @pytest.mark.parametrize('hoist', [True, False])
 def test_chess_tape_equals_oracle_on_rows(chess_bytes, hoist):
     check_scene(chess_bytes, 1024, 1024, [(0, 1), (511, 513), (600, 601), (704, 705)], hoist=hoist)
+
+
+def test_skip_regions_preserve_values(chess_bytes):
+    """SKIPZ / SKIPNZ taken wavefront by wavefront (as the kernels do) vs never taken vs lowering without them."""
+    tape = M.Scene(chess_bytes).lower()
+    assert tape.info['skip_ops'] > 500 and tape.info['bool_ops'] > 3000
+    plain = M.Scene(chess_bytes).lower(skips=False)
+    assert plain.info['skip_ops'] == 0
+    _, want64 = OScene(chess_bytes).render_rows(1024, 1024, 600, 601)
+    taken = tape_eval.render_rows_waves(tape, 1024, 600, 601)
+    assert same_f64(taken, want64)
+    assert same_f64(tape_eval.render_rows(tape, 1024, 600, 601), want64)
+    assert same_f64(tape_eval.render_rows(plain, 1024, 600, 601), want64)
+    # a scene mixing boolean algebra with arithmetic consumers of booleans, ragged width
+    from marayb import max_, min_
+    b1 = step(sub(x(), nat(20))); b2 = step(sub(nat(70), x())); b3 = step(sub(y(), nat(2)))
+    heavy = step(sin(mul(add(mul(x(), x()), mul(y(), nat(3))), div(nat(1), nat(7)))))
+    for k in range(6):
+        heavy = min_(heavy, step(add(mul(x(), nat(k + 1)), sub(y(), nat(40 * k)))))
+    c = [mul(mul(min_(b1, b2), heavy), nat(200)), mul(max_(mul(b1, b3), mul(heavy, sub(nat(1), b2))), add(x(), nat(1))),
+         add(min_(min_(b1, b3), heavy), max_(b2, heavy))]
+    data = encode((100, 5), c)
+    t2 = M.Scene(data).lower()
+    assert t2.info['skip_ops'] >= 2
+    _, w64 = OScene(data).render_rows(100, 5, 0, 5)
+    assert same_f64(tape_eval.render_rows_waves(t2, 100, 0, 5), w64)
+    assert same_f64(tape_eval.render_rows(t2, 100, 0, 5), w64)
 
 
 def test_unfused_chess_tape_equals_oracle(chess_bytes):
