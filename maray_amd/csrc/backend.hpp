@@ -19,9 +19,9 @@ struct Backend {
     // average ms per launch of the pixel kernel, HIP events on the launch stream
     virtual float time_rows(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, void *d8, void *d64, int reps) = 0;
     virtual const char *kernel_name() const = 0;
-    // Tape interpreter only: re-evaluate the 256-pixel tiles whose flag word is
-    // non-zero (tile = row_in_launch * ceil(w/256) + x/256), reading the row values
-    // from `yvals` instead of running the ROW section.  Enqueued on `stream`.
+    // Tape interpreter only: re-evaluate the 256-pixel tiles of the device work list
+    // {count, tile, tile, ...} (tile = row_in_launch * ceil(w/256) + x/256), reading the row
+    // values from `yvals` instead of running the ROW section.  Enqueued on `stream`.
     virtual void render_flagged(uint32_t, uint32_t, uint32_t, void *, void *, void *, const unsigned *, const double *) {
         throw Error{MARAY_E_INTERNAL, "render_flagged is not supported by this backend"};
     }

@@ -42,7 +42,7 @@ struct KArgs {
     double *yout;              // ROW: rows x n_yvals
     double *spill;             // [slot - n_lds_slots][grid_threads]
     const MarayTex *tex;
-    const unsigned *tile_flags;   // optional: only tiles with a non-zero word are evaluated
+    const unsigned *tile_list;    // optional work list {count, tile, tile, ...}: only those tiles are evaluated
     unsigned char *rgb8;
     double *rgb64;
     uint32_t n_ops, n_consts, n_yvals, n_slots, n_lds_slots;
@@ -165,8 +165,9 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_pixels(const KArgs A)
     const uint32_t spill_stride = gridDim.x * BLOCK;
     double *spill_base = A.spill ? A.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
 
-    for (uint32_t tile = blockIdx.x; tile < A.n_tiles; tile += gridDim.x) {
-        if (A.tile_flags && !A.tile_flags[tile]) continue;                 // wave-uniform
+    const uint32_t n_work = A.tile_list ? A.tile_list[0] : A.n_tiles;      // wave-uniform
+    for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const uint32_t tile = A.tile_list ? A.tile_list[1 + wi] : wi;
         const uint32_t r = tile / A.tiles_per_row;                 // row within this launch (uniform)
         const uint32_t x = (tile - r * A.tiles_per_row) * BLOCK + threadIdx.x;
         const uint32_t y = A.y0 + r;
@@ -292,7 +293,7 @@ struct TapeBackend final : Backend {
     }
 
     void launch(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, unsigned char *d8, double *d64, hipStream_t st, bool rows_pass,
-                const unsigned *tile_flags = nullptr, const double *ext_yvals = nullptr) {
+                const unsigned *tile_list = nullptr, const double *ext_yvals = nullptr) {
         (void)h;
         const uint32_t rows = y1 - y0;
         if (!rows || !w) return;
@@ -314,7 +315,7 @@ struct TapeBackend final : Backend {
         }
         KArgs A{};
         A.tape = d_pix_ops; A.consts = d_consts; A.yvals = ext_yvals ? ext_yvals : d_yvals; A.tex = d_tex;
-        A.tile_flags = tile_flags;
+        A.tile_list = tile_list;
         A.rgb8 = d8; A.rgb64 = d64;
         A.n_ops = P.n_pix_ops; A.n_consts = P.n_consts; A.n_yvals = P.n_yvals;
         A.n_slots = P.n_pix_slots; A.n_lds_slots = n_lds_slots;

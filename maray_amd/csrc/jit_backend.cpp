@@ -268,7 +268,7 @@ std::string jit_source(const maray_program &P)
     s += "extern \"C\" __global__ void __launch_bounds__(256" + (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string()) +
          ") maray_jit_pixels(unsigned char *__restrict__ rgb8, double *__restrict__ rgb64,\n"
          "                                                                    const double *__restrict__ yvals, const MarayTex *__restrict__ tex,\n"
-         "                                                                    unsigned *__restrict__ tile_flags,\n"
+         "                                                                    unsigned *__restrict__ tile_list, unsigned tile_base,\n"
          "                                                                    unsigned w, unsigned y0, unsigned n_yvals)\n{\n"
          "    const unsigned x = blockIdx.x * 256u + threadIdx.x;\n"
          "    const unsigned r = blockIdx.y;\n"
@@ -293,7 +293,7 @@ std::string jit_source(const maray_program &P)
          "        }\n"
          "    }\n"
          "    __syncthreads();\n"
-         "    if (threadIdx.x == 0 && mr_slow_tile) tile_flags[r * gridDim.x + blockIdx.x] = 1u;\n"
+         "    if (threadIdx.x == 0 && mr_slow_tile) tile_list[1u + atomicAdd(&tile_list[0], 1u)] = tile_base + r * gridDim.x + blockIdx.x;\n"
          "}\n";
     return s;
 }
@@ -426,16 +426,16 @@ struct JitBackend final : Backend {
         const unsigned gx = (w + 255) / 256;
         const uint64_t n_tiles = (uint64_t)gx * rows_total;
         if (n_tiles > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
-        ensure(d_flags, flags_cap, (size_t)n_tiles);
-        HIP_TRY(hipMemsetAsync(d_flags, 0, (size_t)n_tiles * sizeof(unsigned), st));
+        ensure(d_flags, flags_cap, (size_t)n_tiles + 1);                    // work list {count, tile, ...} of deferred tiles
+        HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(unsigned), st));
         for (uint32_t r0 = 0; r0 < rows_total; r0 += 65535) {          // gridDim.y limit
             const uint32_t rows = std::min<uint32_t>(65535, rows_total - r0);
             unsigned char *p8 = d8 ? d8 + (size_t)r0 * w * 3 : nullptr;
             double *p64 = d64 ? d64 + (size_t)r0 * w * 3 : nullptr;
             const double *yv = d_yvals + (size_t)r0 * n_yvals;
-            unsigned *fl = d_flags + (size_t)r0 * gx;
-            unsigned ww = w, yy0 = y0 + r0;
-            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &ww, &yy0, &n_yvals};
+            unsigned *fl = d_flags;
+            unsigned ww = w, yy0 = y0 + r0, tile_base = r0 * gx;
+            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &ww, &yy0, &n_yvals};
             HIP_TRY(hipModuleLaunchKernel(f_pix, gx, rows, 1, 256, 1, 1, 0, st, args, nullptr));
         }
         if (has_sin) slow->render_flagged(w, y0, y1, d8, d64, st, d_flags, d_yvals);   // no-op unless a tile was deferred
