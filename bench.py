@@ -117,10 +117,16 @@ def main():
     # HBM traffic per launch from the committed PMC profile of this very command (FETCH_SIZE x2 per the gfx950
     # correction of MI355X_MICROARCH.md + WRITE_SIZE); bench.py cannot collect PMC counters itself.
     traffic = None
+    executed = None
     prof = os.path.join(ROOT, 'profiles', 'r1_%s_chess4096_pmc.json' % backend_name)
     if os.path.exists(prof):
         d = json.load(open(prof))['derived']
         traffic = d['hbm_fetch_bytes_x2_gfx950_correction'] + d['hbm_write_bytes']
+        # what the kernel actually issues (committed PMC profile): wave-level short circuits skip most of the
+        # boolean-gated work, so the executed VALU stream is far shorter than the algorithmic op count
+        executed = {'source': os.path.relpath(prof, ROOT), 'valu_insts_per_wave': d['valu_insts_per_wave'],
+                    'salu_insts_per_wave': d['salu_insts_per_wave'],
+                    'cycles_per_valu_inst_per_simd': d['cycles_per_valu_inst_per_simd']}
 
     cpu = None
     if rank == 0 and n_gpus == 1 and args.cpu_seconds > 0:
@@ -154,6 +160,10 @@ def main():
             'roofline': {'bound': 'valu_f64', 'achieved': achieved, 'peak': PEAK_F64_TOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_F64_TOPS, 'traffic': traffic,
                          'kernel_ms': k_ms, 'alg_ops_per_pixel': ALG_OPS_PER_PIXEL,
+                         'note': 'achieved = SURVEY §8(d) algorithmic ops (10,241 per pixel) / kernel time; frac > 1 means '
+                                 'the kernel does less than that census: half of the DAG is boolean algebra evaluated on '
+                                 'lane masks by the scalar unit, and regions gated by a wave-uniformly false AND are skipped',
+                         'executed': executed,
                          'hbm': {'achieved': hbm_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                  'frac': hbm_gbs / PEAK_HBM_GBS, 'bytes_per_pixel': 3}},
             'cpu_baseline': cpu,

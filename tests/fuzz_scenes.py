@@ -1,0 +1,57 @@
+"""Random scene generator for the parity fuzz tests (deterministic per seed)."""
+import random
+
+from marayb import (abs_, add, app, arc, channel, decor, div, exp, image_height, image_width, let_, ln, max_, min_, mul,
+                    nat, neg, recip, sin, sqrt, step, sub, var_id, x, y)
+
+UN = [neg, abs_, recip, sqrt, step, sin, exp, ln]
+BIN = [add, mul, max_, min_]
+
+
+def _leaf(rng, vars_):
+    r = rng.random()
+    if vars_ and r < 0.25: return var_id(rng.choice(vars_))
+    if r < 0.50: return x()
+    if r < 0.70: return y()
+    if r < 0.90: return nat(rng.choice([0, 1, 2, 3, 5, 7, 16, 100, 255, 1024, 10 ** 6, 10 ** 12]))
+    return rng.choice([('Tau',), ('E',)])
+
+
+def _expr(rng, depth, vars_, n_tex):
+    if depth <= 0 or rng.random() < 0.12:
+        return _leaf(rng, vars_)
+    r = rng.random()
+    if r < 0.08:   # scaled coordinate, keeps many arguments in a moderate range
+        return mul(_leaf(rng, vars_), div(nat(1), nat(rng.choice([3, 7, 64, 1000]))))
+    if r < 0.40:
+        f = rng.choice(UN)
+        return f(_expr(rng, depth - 1, vars_, n_tex))
+    if r < 0.80:
+        f = rng.choice(BIN)
+        return f(_expr(rng, depth - 1, vars_, n_tex), _expr(rng, depth - 1, vars_, n_tex))
+    if r < 0.86:   # boolean algebra, the shapes the skip regions look for
+        a = step(_expr(rng, depth - 1, vars_, n_tex)); b = step(_expr(rng, depth - 1, vars_, n_tex))
+        c = rng.choice([min_, max_, mul])(a, rng.choice([b, sub(nat(1), b)]))
+        return c if rng.random() < 0.5 else mul(c, _expr(rng, depth - 2, vars_, n_tex))
+    if r < 0.90 and n_tex:
+        t = rng.randrange(n_tex)
+        sel = rng.choice([channel(t, 0), channel(t, 1), channel(t, 2), image_width(t), image_height(t)])
+        return app(sel, _expr(rng, depth - 1, vars_, n_tex), _expr(rng, depth - 1, vars_, n_tex))
+    if r < 0.93:
+        return arc(_expr(rng, depth - 1, vars_, n_tex))
+    if r < 0.95:
+        return decor(_expr(rng, depth - 1, vars_, n_tex), ['note', 2, ('TokenExpr', x())])
+    # Let with definitions that reference earlier ones (like the compressor's output, src/compressor.rs:226-232)
+    base = rng.randrange(0, 1000) * 10
+    ids, defs = [], []
+    for k in range(rng.randint(1, 4)):
+        defs.append((base + k, _expr(rng, depth - 2, ids[:], n_tex)))
+        ids.append(base + k)
+    return let_(defs, _expr(rng, depth - 1, ids, n_tex))
+
+
+def scene(seed, depth=6, n_tex=0):
+    """Three channel expressions.  Let ids are unique per Let (base chosen at random), so the reference's
+    id-keyed Cache stays value-transparent; scenes that still alias are skipped by the caller."""
+    rng = random.Random(seed)
+    return [_expr(rng, depth, [], n_tex) for _ in range(3)]

@@ -36,6 +36,19 @@ def _sin(a):
     return out
 
 
+def _max(a, b):
+    """f64::max as the oracle defines it: NaN-ignoring, and +0 > -0 (IEEE 754-2019 maximumNumber)."""
+    r = np.where(a > b, a, b)
+    r = np.where(a == b, np.where(np.signbit(a), b, a), r)
+    return np.where(np.isnan(a), b, np.where(np.isnan(b), a, r))
+
+
+def _min(a, b):
+    r = np.where(a < b, a, b)
+    r = np.where(a == b, np.where(np.signbit(a), a, b), r)
+    return np.where(np.isnan(a), b, np.where(np.isnan(b), a, r))
+
+
 def decode(ins):
     ins = int(ins)
     return (ins & 0x7F, (ins >> 7) & 0x1FFF, (ins >> 20) & 0xFFF, (ins >> 32) & 0xFFFF, (ins >> 48) & 0xFFFF)
@@ -92,8 +105,8 @@ def run_section(ops, consts, n_slots, X, Y, yvals, textures, n_out, honor_skips=
             elif op == OP['LN']: r = _vlog(fetch(ra))
             elif op == OP['ADD']: r = fetch(ra) + fetch(rb)
             elif op == OP['MUL']: r = fetch(ra) * fetch(rb)
-            elif op == OP['MAX']: r = np.fmax(fetch(ra), fetch(rb))
-            elif op == OP['MIN']: r = np.fmin(fetch(ra), fetch(rb))
+            elif op == OP['MAX']: r = _max(fetch(ra), fetch(rb))
+            elif op == OP['MIN']: r = _min(fetch(ra), fetch(rb))
             elif op == OP['TEXDIM']:
                 t = textures[aux // 5]
                 r = np.full(shape, float(t.shape[1] if aux % 5 == 3 else t.shape[0]))
