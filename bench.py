@@ -3,9 +3,10 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 is launched under torch.distributed.run with one rank per GPU.  A "step" is one
-pass of the hot path over the rank's whole tile (4096 x 4096 pixels), outputs
-resident in HBM.  Pixels are independent, so ranks own disjoint row tiles and no
-data-path collective is issued (weak scaling: per-GPU work is fixed); the only
+pass of the hot path over the rank's share (4096 x 4096 pixels) of one image of
+the chess scene, outputs resident in HBM.  Pixels are independent, so ranks own
+disjoint rows (interleaved 256-row blocks, for balance) and no data-path
+collective is issued (weak scaling: pixels per GPU are fixed); the only
 collectives are the timing barrier and the max-over-ranks of the elapsed time.
 
 Rank 0 prints ONE JSON line with the metric, the roofline of the dominant kernel
@@ -52,13 +53,22 @@ def main():
         raise SystemExit('bench.py needs a MI355X: no HIP device is visible (there is no CPU fallback)')
     torch.cuda.set_device(local)
     n_gpus = world
+    if world == 1 and os.environ.get('MARAY_BENCH_FAKE_WORLD'):      # rehearse rank r of N on one GPU, no process group
+        n_gpus = int(os.environ['MARAY_BENCH_FAKE_WORLD'])
+        rank = int(os.environ.get('MARAY_BENCH_FAKE_RANK', '0'))
 
     data = open(os.path.join(ROOT, 'tests', 'golden', 'chess.maray'), 'rb').read()
     scene = M.Scene(data)
-    scene.rescale(4, 4)                      # config 3: chess.maray regenerated at 4096 x 4096 (exact power-of-two rescale)
+    # N = 1: config 3, chess.maray regenerated at 4096 x 4096 (exact power-of-two rescale).  N > 1: the same scene
+    # at N x 4096^2 pixels (8192x4096, 8192^2, 16384x8192 = config 4's width), rows dealt to the ranks in interleaved
+    # 256-row blocks so that every rank sees sky and board alike: equal pixels per rank, no data-path collective.
+    from maray_amd.sharding import interleaved_blocks, max_over_ranks, scene_scale
+    sx, sy = scene_scale(n_gpus)
+    scene.rescale(sx, sy)
+    w_img, h_total = scene.size
     tape = scene.lower()
-    from maray_amd.sharding import max_over_ranks, weak_rows
-    y0, y1, h_total = weak_rows(rank, n_gpus, H_TILE)
+    blocks = interleaved_blocks(rank, n_gpus, h_total, 256)
+    rows_mine = sum(b - a for a, b in blocks)
 
     backends = {'tape': M.BACKEND_TAPE, 'tape-smem': M.BACKEND_TAPE_SMEM, 'jit': M.BACKEND_JIT}
     order = ['jit', 'tape-smem', 'tape'] if args.backend == 'auto' else [args.backend]
@@ -75,11 +85,14 @@ def main():
     if ctx is None:
         raise last
 
-    out8 = torch.empty((H_TILE, W, 3), dtype=torch.uint8, device='cuda')
+    out8 = torch.empty((rows_mine, w_img, 3), dtype=torch.uint8, device='cuda')
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        ctx.render_rows_device(W, h_total, y0, y1, d_rgb8=out8.data_ptr(), stream=stream)
+        off = 0
+        for a, b in blocks:
+            ctx.render_rows_device(w_img, h_total, a, b, d_rgb8=out8.data_ptr() + off * w_img * 3, stream=stream)
+            off += b - a
 
     def fence():
         torch.cuda.synchronize()
@@ -97,22 +110,28 @@ def main():
     dt = time.perf_counter() - t0
     dt = max_over_ranks(dist if world > 1 else None, dt, device='cuda')
 
-    px_per_step = W * H_TILE * n_gpus
+    px_per_step = w_img * h_total
     value = px_per_step * args.steps / dt / 1e6
 
-    # roofline of the dominant (pixel) kernel: HIP events on the launch stream, this rank's tile
-    k_ms = ctx.time_rows(W, h_total, y0, y1, d_rgb8=out8.data_ptr(), reps=max(3, min(args.steps, 10)))
-    ops_per_launch = ALG_OPS_PER_PIXEL * W * H_TILE
-    achieved = ops_per_launch / (k_ms * 1e-3) / 1e12
-    hbm_gbs = (W * H_TILE * 3) / (k_ms * 1e-3) / 1e9
+    # roofline of the dominant (pixel) kernel: HIP events on the launch stream, this rank's first block
+    a0, b0 = blocks[0]
+    k_ms = ctx.time_rows(w_img, h_total, a0, b0, d_rgb8=out8.data_ptr(), reps=max(3, min(args.steps, 10)))
+    px_launch = w_img * (b0 - a0)
+    achieved = ALG_OPS_PER_PIXEL * px_launch / (k_ms * 1e-3) / 1e12
+    hbm_gbs = (px_launch * 3) / (k_ms * 1e-3) / 1e9
 
-    # parity spot check of the timed output against the committed golden (every 4th pixel of rows 0..4095 = config 1)
+    # parity spot check of the timed output against the committed golden: pixel (sx*i, sy*j) of the rescaled scene
+    # equals pixel (i, j) of the stored one (config 1) bit for bit
     parity = None
     if rank == 0:
         import hashlib
         g = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'chess_1024.json')))
-        sub = out8[::4, ::4].contiguous().cpu().numpy()
-        parity = hashlib.sha256(sub.tobytes()).hexdigest() == g['rgb8_sha256']
+        if n_gpus == 1:
+            sub = out8[::sy, ::sx].contiguous().cpu().numpy()
+            parity = hashlib.sha256(sub.tobytes()).hexdigest() == g['rgb8_sha256']
+        else:   # rank 0 holds rows [0,256) first: stored rows 0 and 100*... -> check stored row 0
+            sub = out8[0, ::sx].contiguous().cpu().numpy()
+            parity = hashlib.sha256(sub.tobytes()).hexdigest() == g['row_sha256']['0']
 
     # HBM traffic per launch from the committed PMC profile of this very command (FETCH_SIZE x2 per the gfx950
     # correction of MI355X_MICROARCH.md + WRITE_SIZE); bench.py cannot collect PMC counters itself.
@@ -129,10 +148,11 @@ def main():
                     'cycles_per_valu_inst_per_simd': d['cycles_per_valu_inst_per_simd']}
 
     cpu = None
-    if rank == 0 and n_gpus == 1 and args.cpu_seconds > 0:
+    if rank == 0 and n_gpus == 1 and world == 1 and args.cpu_seconds > 0:
         sys.path.insert(0, os.path.join(ROOT, 'tests'))
         from oracle_ffi import Scene as OScene
         o = OScene(scene.encode())
+        W = w_img
         threads = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
         batch = max(16, threads // 2)              # rows per call: keeps every thread busy
         rows, ct = 0, 0.0
@@ -145,15 +165,15 @@ def main():
                'sample': '%d rows x %d px of the same 4096x4096 chess scene (rows 2048..%d), oracle = restated '
                          'ParallelInterpreted (src/render.rs:35-99), %.1f s' % (rows, W, 2048 + rows, ct)}
 
-    if rank == 0:
+    if rank == 0 or (world == 1 and n_gpus > 1):
         line = {
             'metric': 'Mpixels/s on chess.maray @4096x4096',
             'value': value, 'unit': 'Mpixels/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'data/chess.maray rescaled x4 to 4096 px wide (SURVEY.md §8(d) config 3); '
-                                   'each rank evaluates its own 4096x4096-pixel row tile of a 4096 x %d image'
-                                   % h_total,
+            'config': {'workload': 'data/chess.maray rescaled to %d x %d (SURVEY.md §8(d) config 3 at N=1; N x 4096^2 pixels '
+                                   'of the same scene at N>1), rows dealt to the ranks in interleaved 256-row blocks'
+                                   % (w_img, h_total),
                        'backend': backend_name, 'kernel': ctx.kernel_name, 'pixels_per_step': px_per_step,
                        'tape_ops_per_pixel': tape.info['n_pix_ops'], 'parallelism': 'row tiles, no collective',
                        'bit_exact_vs_golden': parity},

@@ -15,6 +15,25 @@ def strong_rows(rank, world, h):
     return (h * rank) // world, (h * (rank + 1)) // world
 
 
+def scene_scale(world):
+    """(sx, sy) multipliers of the stored 1024x1024 scene so that N ranks share one image of N x 4096^2 pixels:
+    N=1 -> 4096x4096, 2 -> 8192x4096, 4 -> 8192x8192, 8 -> 16384x8192 (non powers of two stretch vertically)."""
+    if world & (world - 1) == 0:
+        k = 1
+        while k * k < world:
+            k *= 2
+        return 4 * k, 4 * (world // k)
+    return 4, 4 * world
+
+
+def interleaved_blocks(rank, world, h, block_rows):
+    """Row blocks of `block_rows` dealt round-robin to the ranks: [(y0, y1), ...] for this rank.  Balances
+    data-dependent cost (empty sky vs chess board) without any exchange; with world == 1 it is the whole image."""
+    if world == 1:
+        return [(0, h)]
+    return [(y, min(h, y + block_rows)) for b, y in enumerate(range(0, h, block_rows)) if b % world == rank]
+
+
 def max_over_ranks(dist, value, device=None):
     """MAX all-reduce of a python float (no-op when not initialised)."""
     import torch

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from maray_amd.sharding import max_over_ranks, strong_rows, weak_rows
+from maray_amd.sharding import interleaved_blocks, max_over_ranks, scene_scale, strong_rows, weak_rows
 
 
 def test_row_ranges_partition_the_image():
@@ -23,6 +23,21 @@ def test_row_ranges_partition_the_image():
         rows = [weak_rows(r, world, 4096) for r in range(world)]
         assert rows[-1][1] == rows[-1][2] == 4096 * world
         assert all(b - a == 4096 for a, b, _ in rows)
+
+
+def test_bench_sharding_is_a_balanced_partition():
+    for world in (1, 2, 3, 4, 8):
+        sx, sy = scene_scale(world)
+        w, h = 1024 * sx, 1024 * sy
+        assert w * h == world * 4096 * 4096                      # weak scaling: 4096^2 pixels per rank
+        seen = np.zeros(h, np.int32)
+        for r in range(world):
+            blocks = interleaved_blocks(r, world, h, 256)
+            assert sum(b - a for a, b in blocks) == h // world   # equal rows per rank
+            for a, b in blocks:
+                seen[a:b] += 1
+        assert (seen == 1).all()                                  # every row exactly once
+    assert [scene_scale(n) for n in (1, 2, 4, 8)] == [(4, 4), (8, 4), (8, 8), (16, 8)]
 
 
 def _worker(rank, world, port, data, w, h, out_path):
