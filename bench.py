@@ -37,6 +37,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--backend', default=os.environ.get('MARAY_BENCH_BACKEND', 'auto'))
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='CPU baseline sample budget (0 = skip)')
+    ap.add_argument('--cpu-jit', action='store_true', help='also time the JIT stand-in (scene compiled to native code by cc)')
     args = ap.parse_args()
 
     import torch
@@ -165,6 +166,23 @@ def main():
                'sample': '%d rows x %d px of the same 4096x4096 chess scene (rows 2048..%d), oracle = restated '
                          'ParallelInterpreted (src/render.rs:35-99), %.1f s' % (rows, W, 2048 + rows, ct)}
 
+    cpu_jit = None
+    if cpu is not None and args.cpu_jit:
+        from oracle_ffi import JitBaseline
+        t = time.perf_counter()
+        jb = JitBaseline(o)
+        build_s = time.perf_counter() - t
+        rows, ct = 0, 0.0
+        while ct < args.cpu_seconds and 2048 + rows + batch <= H_TILE:
+            t = time.perf_counter()
+            jb.render_rows(W, 2048 + rows, 2048 + rows + batch, threads=threads)
+            ct += time.perf_counter() - t
+            rows += batch
+        cpu_jit = {'value': W * rows / ct / 1e6, 'unit': 'Mpixels/s', 'cores': threads, 'kind': 'port',
+                   'sample': '%d rows x %d px, scene emitted as straight-line C like src/wasm.rs gen_expr (un-shared, one '
+                             'function per channel, out-of-line recip/step/sin), cc -O2, build %.1f s, run %.1f s'
+                             % (rows, W, build_s, ct)}
+
     if rank == 0 or (world == 1 and n_gpus > 1):
         line = {
             'metric': 'Mpixels/s on chess.maray @4096x4096',
@@ -187,6 +205,7 @@ def main():
                          'hbm': {'achieved': hbm_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                  'frac': hbm_gbs / PEAK_HBM_GBS, 'bytes_per_pixel': 3}},
             'cpu_baseline': cpu,
+            'cpu_baseline_jit': cpu_jit,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

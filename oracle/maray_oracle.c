@@ -754,3 +754,96 @@ int oracle_render_rows(oracle_scene *s, uint32_t w, uint32_t h, uint32_t y0, uin
     if (fault) { set_err("App id out of range of Runtime.functions (reference panics, src/lib.rs:665)"); return -3; }
     return 0;
 }
+
+
+/* ---- "JIT" baseline: the scene as straight-line C --------------------------------------------
+ * Stand-in for the reference's wasmer JIT (src/wasm.rs:89-158, src/render.rs:102-192), which
+ * cannot be built here (no Rust, no wasmer).  Mirrors gen_expr: one un-shared function per
+ * channel, Let variables become locals assigned in definition order (gen_vars :77-86), neg /
+ * sqrt / add / mul / max / min are native ops (:41-42,:56-59; max/min with wasm's NaN-propagating
+ * semantics), abs / recip / step / sin / exp / ln / app are out-of-line calls like the host imports
+ * (:8-34,:40-47).  Rows are pulled from a shared counter by N threads (render.rs:150-183).
+ * BASELINE ONLY (bench.py --cpu-jit): compiled by the system cc, never part of the product. */
+typedef struct { char *p; size_t n, cap; } SB;
+static void sb_put(SB *b, const char *s)
+{
+    size_t k = strlen(s);
+    if (b->n + k + 1 > b->cap) { b->cap = (b->cap + k + 1) * 2; b->p = (char *)realloc(b->p, b->cap); }
+    memcpy(b->p + b->n, s, k + 1); b->n += k;
+}
+static void sb_fmt_u64(SB *b, const char *pre, uint64_t v, const char *post)
+{
+    char t[64]; snprintf(t, sizeof t, "%s%llu%s", pre, (unsigned long long)v, post); sb_put(b, t);
+}
+
+static void emit_locals(SB *b, const OExpr *e)
+{
+    if (!e) return;
+    if (e->tag == T_LET)
+        for (uint64_t i = 0; i < e->ctx->n; i++) { sb_fmt_u64(b, "    double v", e->ctx->ids[i], " = 0;\n"); emit_locals(b, e->ctx->defs[i]); }
+    emit_locals(b, e->a); emit_locals(b, e->b);
+}
+
+static void emit_expr(SB *b, const OExpr *e)
+{
+    static const char *un[] = {"-", "imp_abs", "imp_recip", "__builtin_sqrt", "imp_step", "imp_sin", "imp_exp", "imp_ln"};
+    switch (e->tag) {
+    case T_ARC: case T_DECOR: emit_expr(b, e->a); break;
+    case T_X: sb_put(b, "x"); break;
+    case T_Y: sb_put(b, "y"); break;
+    case T_TAU: sb_put(b, "6.283185307179586"); break;
+    case T_E: sb_put(b, "2.718281828459045"); break;
+    case T_VAR: sb_fmt_u64(b, "v", e->u, ""); break;
+    case T_NAT: sb_fmt_u64(b, "", e->u, ".0"); break;
+    case T_NEG: case T_ABS: case T_RECIP: case T_SQRT: case T_STEP: case T_SIN: case T_EXP: case T_LN:
+        sb_put(b, un[e->tag - T_NEG]); sb_put(b, "("); emit_expr(b, e->a); sb_put(b, ")"); break;
+    case T_ADD: case T_MUL:
+        sb_put(b, "("); emit_expr(b, e->a); sb_put(b, e->tag == T_ADD ? " + " : " * "); emit_expr(b, e->b); sb_put(b, ")"); break;
+    case T_MAX: case T_MIN:
+        sb_put(b, e->tag == T_MAX ? "wasm_max(" : "wasm_min("); emit_expr(b, e->a); sb_put(b, ", "); emit_expr(b, e->b); sb_put(b, ")"); break;
+    case T_LET:   /* GNU statement expression: definitions in order, then the body */
+        sb_put(b, "({ ");
+        for (uint64_t i = 0; i < e->ctx->n; i++) { sb_fmt_u64(b, "v", e->ctx->ids[i], " = "); emit_expr(b, e->ctx->defs[i]); sb_put(b, ";\n      "); }
+        emit_expr(b, e->a); sb_put(b, "; })");
+        break;
+    case T_APP: sb_fmt_u64(b, "imp_app(", e->app_id, ", "); emit_expr(b, e->a); sb_put(b, ", "); emit_expr(b, e->b); sb_put(b, ")"); break;
+    }
+}
+
+/* Returns a malloc'd C translation unit (free with oracle_free).  fix_color is applied first. */
+char *oracle_scene_emit_c(oracle_scene *s)
+{
+    oracle_fix_color(s);
+    SB b = {NULL, 0, 0};
+    sb_put(&b,
+        "#include <math.h>\n#include <pthread.h>\n#include <stdint.h>\n"
+        "#define NI __attribute__((noinline)) static\n"
+        "NI double imp_abs(double v) { return fabs(v); }\nNI double imp_sin(double v) { return sin(v); }\n"
+        "NI double imp_exp(double v) { return exp(v); }\nNI double imp_ln(double v) { return log(v); }\n"
+        "NI double imp_recip(double v) { return 1.0 / v; }\nNI double imp_step(double v) { return v >= 0.0 ? 1.0 : 0.0; }\n"
+        "NI double imp_app(uint32_t id, double a, double b) { (void)id; (void)a; (void)b; return 0.0; }\n"
+        "static inline double wasm_max(double a, double b) { if (a != a || b != b) return NAN; if (a == b) return signbit(a) ? b : a; return a > b ? a : b; }\n"
+        "static inline double wasm_min(double a, double b) { if (a != a || b != b) return NAN; if (a == b) return signbit(a) ? a : b; return a < b ? a : b; }\n"
+        "static inline uint8_t cast_u8(double v) { if (!(v > 0.0)) return 0; if (v >= 255.0) return 255; return (uint8_t)v; }\n");
+    for (int c = 0; c < 3; c++) {
+        char t[64]; snprintf(t, sizeof t, "NI double ch%d(double x, double y)\n{\n", c); sb_put(&b, t);
+        emit_locals(&b, s->color[c]);
+        sb_put(&b, "    return "); emit_expr(&b, s->color[c]); sb_put(&b, ";\n}\n");
+    }
+    sb_put(&b,
+        "typedef struct { uint32_t w, y0, y1; uint8_t *rgb8; volatile uint32_t *next; } Job;\n"
+        "static void *worker(void *arg) {\n    Job *j = (Job *)arg;\n    for (;;) {\n"
+        "        uint32_t y = __atomic_fetch_add(j->next, 1u, __ATOMIC_RELAXED);\n        if (y >= j->y1) break;\n"
+        "        uint8_t *row = j->rgb8 + (size_t)(y - j->y0) * j->w * 3;\n"
+        "        for (uint32_t x = 0; x < j->w; x++) {\n"
+        "            row[x * 3] = cast_u8(ch0((double)x, (double)y));\n            row[x * 3 + 1] = cast_u8(ch1((double)x, (double)y));\n"
+        "            row[x * 3 + 2] = cast_u8(ch2((double)x, (double)y));\n        }\n    }\n    return 0;\n}\n"
+        "int jit_render_rows(uint32_t w, uint32_t y0, uint32_t y1, int threads, uint8_t *rgb8) {\n"
+        "    volatile uint32_t next = y0;\n    Job j = { w, y0, y1, rgb8, &next };\n    pthread_t th[256];\n"
+        "    if (threads < 1) threads = 1;\n    if (threads > 256) threads = 256;\n"
+        "    for (int i = 0; i < threads; i++) pthread_create(&th[i], 0, worker, &j);\n"
+        "    for (int i = 0; i < threads; i++) pthread_join(th[i], 0);\n    return 0;\n}\n");
+    return b.p;
+}
+
+void oracle_free(void *p) { free(p); }

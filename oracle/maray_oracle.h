@@ -91,6 +91,13 @@ int oracle_render_rows(oracle_scene *s, uint32_t w, uint32_t h, uint32_t y0, uin
                        const oracle_texture *tex, uint32_t n_tex, int threads,
                        uint8_t *rgb8, double *rgb64);
 
+/* CPU baseline only: the scene as a straight-line C translation unit — a stand-in for the
+ * reference's wasmer JIT (src/wasm.rs:89-158; one un-shared function per channel, host-import
+ * style out-of-line calls).  malloc'd; release with oracle_free.  Exports
+ * `int jit_render_rows(uint32_t w, uint32_t y0, uint32_t y1, int threads, uint8_t *rgb8)`. */
+char *oracle_scene_emit_c(oracle_scene *s);
+void oracle_free(void *p);
+
 /* Rust `f64 as u8` (saturating, NaN -> 0, truncation toward zero). */
 uint8_t oracle_cast_u8(double v);
 

@@ -49,6 +49,9 @@ def lib():
     L.oracle_eval2.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_uint32]
     L.oracle_render_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                      C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    L.oracle_scene_emit_c.restype = C.c_void_p
+    L.oracle_scene_emit_c.argtypes = [C.c_void_p]
+    L.oracle_free.argtypes = [C.c_void_p]
     L.oracle_cast_u8.restype = C.c_uint8
     L.oracle_cast_u8.argtypes = [C.c_double]
     L.oracle_op_unary.restype = C.c_double
@@ -128,6 +131,40 @@ class Scene:
         if rc != 0:
             raise RuntimeError(lib().oracle_last_error().decode())
         return rgb8, rgb64
+
+
+class JitBaseline:
+    """The scene compiled to native code by the system cc — stand-in for the reference's wasmer JIT
+    (src/wasm.rs, src/render.rs:102-192).  CPU baseline for bench.py --cpu-jit; textures unsupported."""
+
+    def __init__(self, scene, cache_dir=None, opt='-O2'):
+        import hashlib
+        import tempfile
+        p = lib().oracle_scene_emit_c(scene._h)
+        src = C.string_at(p)
+        lib().oracle_free(p)
+        d = cache_dir or os.path.join(ORACLE_DIR, '_build')
+        os.makedirs(d, exist_ok=True)
+        key = hashlib.sha256(src + opt.encode()).hexdigest()[:16]
+        so = os.path.join(d, 'jit_%s.so' % key)
+        if not os.path.exists(so):
+            c = os.path.join(d, 'jit_%s.c' % key)
+            with open(c, 'wb') as f:
+                f.write(src)
+            tmp = tempfile.mktemp(suffix='.so', dir=d)
+            subprocess.check_call(['cc', opt, '-ffp-contract=off', '-fno-fast-math', '-fno-builtin-sin', '-fno-builtin-exp',
+                                   '-fno-builtin-log', '-shared', '-fPIC', '-w', c, '-o', tmp, '-lm', '-lpthread'])
+            os.replace(tmp, so)
+        self.so = so
+        self._lib = C.CDLL(so)
+        self._lib.jit_render_rows.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+
+    def render_rows(self, w, y0, y1, threads=None):
+        rgb8 = np.zeros((y1 - y0, w, 3), np.uint8)
+        if threads is None:
+            threads = os.cpu_count() or 1
+        self._lib.jit_render_rows(w, y0, y1, threads, rgb8.ctypes.data)
+        return rgb8
 
 
 def eval1(expr, xv, yv=0.0):

@@ -57,3 +57,13 @@ def test_chess_full_image_vs_png_and_golden_hash(chess_bytes):
     assert hashlib.sha256(rgb8.tobytes()).hexdigest() == g['rgb8_sha256']
     # f64 plane: values are exactly 0.0 or 255.0
     assert set(np.unique(rgb64)) <= {0.0, 255.0}
+
+
+def test_jit_standin_baseline_matches_interpreter(chess_bytes, tmp_path):
+    """The CPU "JIT" baseline (scene compiled by cc, mirrors src/wasm.rs) renders what the interpreter renders."""
+    from oracle_ffi import JitBaseline
+    from marayb import add, div, encode, let_, mul, nat, sin, step, var_id, x, y
+    c = [mul(step(sin(div(x(), nat(3)))), nat(200)), let_([(0, add(x(), y())), (1, mul(var_id(0), var_id(0)))], div(var_id(1), nat(9))), y()]
+    s = Scene(encode((40, 8), c))
+    want, _ = s.render_rows(40, 8, 0, 8)
+    assert np.array_equal(JitBaseline(s, cache_dir=str(tmp_path)).render_rows(40, 0, 8, threads=2), want)
