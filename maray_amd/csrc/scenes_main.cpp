@@ -1,0 +1,88 @@
+// scenes_main.cpp — `maray_scenes OUTDIR`: writes the benchmark / test scenes of SURVEY.md §8(d)
+// as `.maray` files with the C++ builders (include/maray_builders.hpp).  Counterpart of the
+// reference's scene-generating examples (examples/chess.rs, test.rs, test6.rs, test7.rs).
+#include <cstdio>
+#include <string>
+
+#include "maray_builders.hpp"
+
+using namespace maray_build;
+
+// Config 2: radial gradient, c = Sqrt(X*X + Y*Y)
+static Color radial() { Expr c = sqrt(add(mul(x(), x()), mul(y(), y()))); return {c, c, c}; }
+
+// Config 3b: every computing variant, one phase per channel
+static Color all_ops(uint64_t w, uint64_t h)
+{
+    Expr u = sub(div(x(), nat(w)), div(nat(1), nat(2)));
+    Expr v = sub(div(y(), nat(h)), div(nat(1), nat(2)));
+    Expr r = sqrt(add(mul(u, u), mul(v, v)));
+    Color out;
+    for (uint64_t k = 0; k < 3; k++) {
+        Expr s = sin(add(mul(ln(add(nat(1), r)), nat(8)), nat(k)));
+        Expr e_ = exp(neg(abs(mul(u, v))));
+        out[k] = clamp_u8(mul(nat(255), add(div(nat(1), nat(2)), mul(mul(div(nat(1), nat(2)), s), e_))));
+    }
+    return out;
+}
+
+// Config 5 (pattern of examples/test6.rs:5-9): two textures
+static Color textured(uint64_t w)
+{
+    Color out;
+    for (uint32_t c = 0; c < 3; c++) {
+        Expr a = app(channel(0, c), mul(x(), div(nat(1), nat(4))), mul(y(), div(nat(1), nat(4))));
+        Expr b = app(channel(1, c), mul(add(nat(w), neg(x())), div(nat(1), nat(2))), mul(y(), div(nat(1), nat(8))));
+        Expr e_ = max(a, b);
+        if (c == 2) e_ = mul(e_, div(app(image_width(1), x(), y()), app(image_width(1), nat(0), nat(0))));
+        out[c] = e_;
+    }
+    return out;
+}
+
+// examples/chess.rs:5-50 without `.simplify(mem).compress(mem)` (authoring-time tools, out of scope):
+// an 8x8 grid of quads in perspective with a chess texture.
+static Color chess_board(uint64_t size)
+{
+    Point2 p = {div(x(), nat(size)), div(y(), nat(size))};
+    Expr texture = set_unit_square(chess(8));
+    Grid2 grid{8, 8};
+    std::array<Point2, 4> quad = {Point2{recip(nat(5)), recip(nat(2))}, Point2{sub(nat(1), recip(nat(5))), recip(nat(2))},
+                                  Point2{nat(0), sub(nat(1), recip(nat(5)))}, Point2{nat(1), sub(nat(1), recip(nat(5)))}};
+    Expr shape = nat(0);
+    for (uint64_t i = 0; i < 8; i++)
+        for (uint64_t j = 0; j < 8; j++) {
+            auto cell = grid.cell(i, j, quad);
+            TriPair t = quad_to_tri(cell.first, cell.second);
+            Expr s1 = subst2(mul(inside_triangle(t.tri[0], {x(), y()}), subst2(texture, to_uv(t.tri[0], t.uv[0], {x(), y()}))), p);
+            Expr s2 = subst2(mul(inside_triangle(t.tri[1], {x(), y()}), subst2(texture, to_uv(t.tri[1], t.uv[1], {x(), y()}))), p);
+            shape = set_or(shape, set_or(s1, s2));
+        }
+    Expr c = mul(shape, nat(255));
+    return {c, c, c};
+}
+
+// examples/test.rs:9-27 without simplify/compress: rounded box XOR circle
+static Color sdf(uint64_t size)
+{
+    Point2 p = {div(x(), nat(size)), div(y(), nat(size))};
+    Point2 center = {half(), half()};
+    Expr tenth = div(nat(1), nat(10));
+    Expr a = translate(sd_inside(sd_rounded_box({div(half(), nat(2)), half()}, {tenth, tenth, tenth, tenth})), center);
+    Expr b = translate(sd_inside(sd_circle(recip(nat(3)))), center);
+    Expr c = mul(subst2(set_xor(a, b), p), nat(255));
+    return {c, c, c};
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 2) { fprintf(stderr, "usage: maray_scenes OUTDIR\n"); return 2; }
+    const std::string d = std::string(argv[1]) + "/";
+    bool ok = save(d + "radial_1024.maray", 1024, 1024, radial())
+           && save(d + "allops_4096.maray", 4096, 4096, all_ops(4096, 4096))
+           && save(d + "textured_4096.maray", 4096, 4096, textured(4096))
+           && save(d + "sdf_512.maray", 512, 512, sdf(512))
+           && save(d + "chess_board_1024.maray", 1024, 1024, chess_board(1024));
+    if (!ok) { fprintf(stderr, "cannot write into %s\n", argv[1]); return 1; }
+    return 0;
+}
