@@ -146,7 +146,9 @@ def main():
         # boolean-gated work, so the executed VALU stream is far shorter than the algorithmic op count
         executed = {'source': os.path.relpath(prof, ROOT), 'valu_insts_per_wave': d['valu_insts_per_wave'],
                     'salu_insts_per_wave': d['salu_insts_per_wave'],
-                    'cycles_per_valu_inst_per_simd': d['cycles_per_valu_inst_per_simd']}
+                    'cycles_per_valu_inst_per_simd': d['cycles_per_valu_inst_per_simd'],
+                    # a wave64 f64 VALU op occupies its SIMD for 4 cycles, a 32-bit one for 2: issue-port occupancy bounds
+                    'valu_port_busy_frac_bounds': [2.0 / d['cycles_per_valu_inst_per_simd'], 4.0 / d['cycles_per_valu_inst_per_simd']]}
 
     cpu = None
     if rank == 0 and n_gpus == 1 and world == 1 and args.cpu_seconds > 0:
