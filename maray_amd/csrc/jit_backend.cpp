@@ -244,7 +244,7 @@ std::string jit_source_rows(const maray_program &P)
 // reduction here (a call site per Sin op would force every live value through
 // scratch): the tile is flagged instead and re-evaluated by the tape interpreter
 // kernel afterwards, so the final raster is identical.
-std::string jit_source(const maray_program &P)
+std::string jit_source(const maray_program &P, int min_waves_arg)
 {
     validate_program(P);
     Emitter E(P);
@@ -256,7 +256,7 @@ std::string jit_source(const maray_program &P)
     // tuning knobs (environment): MARAY_JIT_YLDS=0/1, MARAY_JIT_WAVES=<min waves per SIMD for __launch_bounds__>
     const char *env_ylds = getenv("MARAY_JIT_YLDS");
     const char *env_waves = getenv("MARAY_JIT_WAVES");
-    const int min_waves = env_waves ? atoi(env_waves) : 4;   // chess @4096^2: 4 -> 3.54 ms, 0 -> 3.95 ms, 6 -> 4.56 ms
+    const int min_waves = env_waves ? atoi(env_waves) : min_waves_arg;
     const bool y_lds = P.n_yvals > 0 && P.n_yvals <= 4096 && !(env_ylds && env_ylds[0] == '0');
     if (y_lds) E.yv_name = "mr_ylds";
     if (y_lds) s += "__shared__ double mr_ylds[" + std::to_string(P.n_yvals) + "];\n";
@@ -379,13 +379,24 @@ struct JitBackend final : Backend {
         }
         std::vector<char> code, code_rows;
         std::string log;
-        jit_compile(jit_source(prog), code, log);
+        // Occupancy: ask for 8 waves per SIMD (<= 64 VGPRs; chess @4096^2: 1.02 ms vs 1.13 ms at 4); if that
+        // costs more than a few spill slots, rebuild for 4 waves per SIMD (<= 128 VGPRs).
+        jit_compile(jit_source(prog, 8), code, log);
+        HIP_TRY(hipModuleLoadData(&mod, code.data()));
+        HIP_TRY(hipModuleGetFunction(&f_pix, mod, "maray_jit_pixels"));
+        int scratch = 0;
+        HIP_TRY(hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f_pix));
+        if (scratch > 256 && !getenv("MARAY_JIT_WAVES")) {
+            (void)hipModuleUnload(mod);
+            mod = nullptr;
+            jit_compile(jit_source(prog, 4), code, log);
+            HIP_TRY(hipModuleLoadData(&mod, code.data()));
+            HIP_TRY(hipModuleGetFunction(&f_pix, mod, "maray_jit_pixels"));
+        }
         if (prog.n_row_ops) jit_compile(jit_source_rows(prog), code_rows, log);
         slow = make_tape_backend(dev, prog, tex, n_tex, false);
         P = prog;
         P.consts = nullptr; P.row_ops = nullptr; P.pix_ops = nullptr;
-        HIP_TRY(hipModuleLoadData(&mod, code.data()));
-        HIP_TRY(hipModuleGetFunction(&f_pix, mod, "maray_jit_pixels"));
         if (prog.n_row_ops) {
             HIP_TRY(hipModuleLoadData(&mod_rows, code_rows.data()));
             HIP_TRY(hipModuleGetFunction(&f_rows, mod_rows, "maray_jit_rows"));
