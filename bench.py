@@ -67,7 +67,7 @@ def main():
     sx, sy = scene_scale(n_gpus)
     scene.rescale(sx, sy)
     w_img, h_total = scene.size
-    tape = scene.lower()
+    tape = scene.lower(row_guards=os.environ.get('MARAY_BENCH_ROW_GUARDS', '1') != '0')
     blocks = interleaved_blocks(rank, n_gpus, h_total, 256)
     rows_mine = sum(b - a for a, b in blocks)
 

@@ -87,7 +87,8 @@ typedef struct maray_lower_opts {
                               op census of SURVEY.md §8(d)); 0 = canonicalise a+b/b+a etc. (default) */
     uint32_t no_fuse;      /* 1 = keep Step(Sin(a)) as two ops; 0 = fuse into MARAY_OP_STEPSIN (default) */
     uint32_t no_skips;     /* 1 = do not emit SKIPZ / SKIPNZ wave-level short circuits; 0 = emit them (default) */
-    uint32_t reserved[4];
+    uint32_t no_row_guards; /* 1 = no row-level SKIPZ ops (guards that are y values: bounds of a boolean over a whole row) */
+    uint32_t reserved[3];
 } maray_lower_opts;
 
 typedef struct maray_tape_info {

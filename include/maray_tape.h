@@ -31,7 +31,8 @@
  *   kind 1 CONST  consts[index]
  *   kind 2 YVAL   yv[index] of the current row (PIXEL section only)
  *   kind 3 SPEC   index 0 = X (pixel x as f64), 1 = Y (row y as f64),
- *                 2 = ACC (result of the immediately preceding op)
+ *                 2 = ACC (result of the immediately preceding op),
+ *                 3 = XMAX (ROW section only: (w - 1) as f64, the x of a row's last pixel)
  *
  * Every op also leaves its result in ACC.  An op with dst == MARAY_DST_NONE
  * is consumed only through ACC by the next op.
@@ -85,7 +86,7 @@ enum {
 #define MARAY_MAX_INDEX 0x3FFFu
 
 enum { MARAY_K_SLOT = 0, MARAY_K_CONST = 1, MARAY_K_YVAL = 2, MARAY_K_SPEC = 3 };
-enum { MARAY_SPEC_X = 0, MARAY_SPEC_Y = 1, MARAY_SPEC_ACC = 2 };
+enum { MARAY_SPEC_X = 0, MARAY_SPEC_Y = 1, MARAY_SPEC_ACC = 2, MARAY_SPEC_XMAX = 3 };
 
 #define MARAY_REF(kind, index) ((uint32_t)(((kind) << 14) | ((index) & 0x3FFFu)))
 #define MARAY_REF_KIND(r) (((r) >> 14) & 3u)

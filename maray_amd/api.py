@@ -39,7 +39,7 @@ class Texture(C.Structure):
 
 
 class LowerOpts(C.Structure):
-    _fields_ = [('hoist_rows', C.c_uint32), ('plain_cse', C.c_uint32), ('no_fuse', C.c_uint32), ('no_skips', C.c_uint32), ('reserved', C.c_uint32 * 4)]
+    _fields_ = [('hoist_rows', C.c_uint32), ('plain_cse', C.c_uint32), ('no_fuse', C.c_uint32), ('no_skips', C.c_uint32), ('no_row_guards', C.c_uint32), ('reserved', C.c_uint32 * 3)]
 
 
 class CtxOpts(C.Structure):
@@ -200,19 +200,20 @@ class Scene:
     def rescale(self, sx, sy):
         _check(lib().maray_scene_rescale(self._h, sx, sy))
 
-    def lower(self, hoist_rows=True, plain_cse=False, fuse=True, skips=True):
-        return Tape(self, hoist_rows, plain_cse, fuse, skips)
+    def lower(self, hoist_rows=True, plain_cse=False, fuse=True, skips=True, row_guards=True):
+        return Tape(self, hoist_rows, plain_cse, fuse, skips, row_guards)
 
 
 class Tape:
     """Lowered program (include/maray_tape.h)."""
 
-    def __init__(self, scene, hoist_rows=True, plain_cse=False, fuse=True, skips=True):
+    def __init__(self, scene, hoist_rows=True, plain_cse=False, fuse=True, skips=True, row_guards=True):
         o = LowerOpts()
         o.hoist_rows = 1 if hoist_rows else 0
         o.plain_cse = 1 if plain_cse else 0
         o.no_fuse = 0 if fuse else 1
         o.no_skips = 0 if skips else 1
+        o.no_row_guards = 0 if row_guards else 1
         h = C.c_void_p()
         _check(lib().maray_lower(scene._h, C.byref(o), C.byref(h)))
         self._h = h

@@ -113,7 +113,8 @@ void validate_program(const maray_program &p)
                 case MARAY_K_SLOT: ok = idx < n_slots && written[idx]; break;
                 case MARAY_K_CONST: ok = idx < p.n_consts; break;
                 case MARAY_K_YVAL: ok = pixel && idx < p.n_yvals; break;
-                default: ok = idx <= MARAY_SPEC_ACC && (idx != MARAY_SPEC_ACC || have_acc) && (idx != MARAY_SPEC_X || pixel);
+                default: ok = idx <= MARAY_SPEC_XMAX && (idx != MARAY_SPEC_ACC || have_acc) && (idx != MARAY_SPEC_X || pixel) &&
+                              (idx != MARAY_SPEC_XMAX || !pixel);
                 }
                 if (!ok) throw Error{MARAY_E_ARG, "operand out of range or read before write at op " + std::to_string(i)};
             }
@@ -326,8 +327,10 @@ void maray_hip_ctx_free(maray_ctx *c)
 
 static void check_rows(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1)
 {
-    (void)w;
     if (y0 > y1 || y1 > h) throw Error{MARAY_E_ARG, "row range out of bounds"};
+    // the lowering's interval analysis (bounded Sin arguments, row bounds) covers x, y < MARAY_DOMAIN_MAX
+    if (w > MARAY_DOMAIN_MAX || y1 > MARAY_DOMAIN_MAX)
+        throw Error{MARAY_E_LIMIT, "image exceeds " + std::to_string(MARAY_DOMAIN_MAX) + " pixels in x or y"};
 }
 
 int maray_hip_render_rows(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint8_t *rgb8, double *rgb64)

@@ -76,7 +76,7 @@ __device__ __forceinline__ void run_tape(const KArgs &A, const uint64_t *tape_ld
         if (kind == MARAY_K_SLOT) return idx < n_lds ? slots[idx * BLOCK + tid] : spill_base[(size_t)(idx - n_lds) * spill_stride];
         if (kind == MARAY_K_CONST) return TAPE_LDS ? consts_lds[idx] : consts_k[idx];
         if (kind == MARAY_K_YVAL) return yrow_k[idx];
-        return idx == MARAY_SPEC_X ? X : (idx == MARAY_SPEC_Y ? Y : acc);
+        return idx == MARAY_SPEC_X ? X : (idx == MARAY_SPEC_Y ? Y : (idx == MARAY_SPEC_ACC ? acc : (double)(A.w - 1u)));
     };
 
     for (uint32_t pc = 0; pc < A.n_ops; ++pc) {

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -37,6 +38,12 @@ extern "C" const char maray_embedded_libm_tables_h[];
 namespace maray {
 
 namespace {
+
+bool jit_row_guards_enabled()
+{
+    const char *e_ = getenv("MARAY_JIT_ROW_GUARDS");
+    return e_ && e_[0] == '1';
+}
 
 std::string lit(double v)
 {
@@ -65,6 +72,8 @@ struct Emitter {
     std::string out;
     std::vector<Val> vals;   // one per op of the current section
     std::string yv_name = "yv";
+    bool ignore_row_guards = false;
+    uint32_t guard_first = 0, guard_words = 0;   // y values >= guard_first are SKIP guards packed as bits (32 per word)
     explicit Emitter(const maray_program &p) : P(p) {}
 
     void section(const uint64_t *ops, uint32_t n, uint32_t n_slots, bool pixel, const char *prefix)
@@ -93,7 +102,7 @@ struct Emitter {
             case MARAY_K_YVAL: t.d = yv_name + "[" + std::to_string(idx) + "]"; return &t;
             default:
                 if (idx == MARAY_SPEC_ACC) return &vals[acc];
-                t.d = idx == MARAY_SPEC_X ? "X" : "Y";
+                t.d = idx == MARAY_SPEC_X ? "X" : (idx == MARAY_SPEC_Y ? "Y" : "XMAX");
                 return &t;
             }
         };
@@ -121,12 +130,32 @@ struct Emitter {
                 const uint32_t end = i + aux;
                 snprintf(name, sizeof name, "%s%u", prefix, end);
                 const bool as_bool = va->kind == BOOL;
+                const uint32_t gref = MARAY_INS_A(ins);
+                const bool row_guard = pixel && MARAY_REF_KIND(gref) == MARAY_K_YVAL;
+                if (row_guard && ignore_row_guards) continue;      // legal: an evaluator may ignore any SKIP op
                 std::string cond;
-                if (as_bool) cond = nz ? "!" + va->b : va->b;
+                if (row_guard && !nz && guard_words && MARAY_REF_INDEX(gref) >= guard_first) {
+                    // a row bound: one bit of a guard word that sits in an SGPR since the kernel's prologue
+                    const uint32_t k = MARAY_REF_INDEX(gref) - guard_first;
+                    cond = "(gw" + std::to_string(k / 32) + " & " + std::to_string(1u << (k % 32)) + "u) != 0u";
+                } else if (row_guard) {
+                    // a y value is uniform over the block: test its bits on the scalar unit, no ballot, no VALU
+                    const std::string k = std::to_string(MARAY_REF_INDEX(gref));
+                    cond = nz ? "!(yw[2 * " + k + " + 1] == 0x3ff00000u && yw[2 * " + k + "] == 0u)"
+                              : "((yw[2 * " + k + " + 1] << 1) | yw[2 * " + k + "]) != 0u";
+                } else if (as_bool) cond = nz ? "!" + va->b : va->b;
                 else cond = "(" + dbl(va, "m", i, 0) + (nz ? " != 1.0)" : " != 0.0)");
-                out += as_bool ? "    bool b" + std::string(name) + ";\n" : "    double " + std::string(name) + ";\n";
-                out += "    if (__builtin_amdgcn_ballot_w64(" + cond + ") != 0ull) {\n";
-                open.push_back(Open{end, as_bool, nz});
+                // several regions may end at one op (a row-level guard around a wave-level one): one variable
+                bool typed_bool = as_bool;
+                bool declared = false;
+                for (const Open &o : open) if (o.end == end) { declared = true; typed_bool = o.as_bool; }
+                if (!declared) out += typed_bool ? "    bool b" + std::string(name) + ";\n" : "    double " + std::string(name) + ";\n";
+                // regions are entered rarely (chess: 2-20 %): mark them unlikely so that the block placement keeps the
+                // skip path as the fall-through and moves the region bodies out of line (taken jumps stall on instruction fetch)
+                const bool cold = !getenv("MARAY_JIT_NO_EXPECT");
+                const std::string test = row_guard ? cond : "__builtin_amdgcn_ballot_w64(" + cond + ") != 0ull";
+                out += cold ? "    if (__builtin_expect(" + test + ", 0)) {\n" : "    if (" + test + ") {\n";
+                open.push_back(Open{end, typed_bool, nz});
                 continue;
             }
             if (op == MARAY_OP_OUT) {
@@ -200,7 +229,12 @@ struct Emitter {
                     out += "    " + self + " = " + ee + ";\n    } else " + self + (o.nz ? " = 1.0;\n" : " = 0.0;\n");
                     r.kind = DBL; r.d = self;
                 }
-                if (!open.empty() && open.back().end == i) throw Error{MARAY_E_ARG, "two skip regions end at one op"};
+                while (!open.empty() && open.back().end == i) {     // enclosing regions that end here too
+                    const Open o2 = open.back();
+                    open.pop_back();
+                    out += o.as_bool ? "    } else b" + self + (o2.nz ? " = true;\n" : " = false;\n")
+                                     : "    } else " + self + (o2.nz ? " = 1.0;\n" : " = 0.0;\n");
+                }
             } else if (!be.empty()) {
                 out += "    const bool b" + self + " = " + be + ";\n";
                 r.kind = BOOL; r.b = "b" + self;
@@ -227,14 +261,27 @@ std::string jit_source_rows(const maray_program &P)
     s += "// generated by libmaray_hip (jit_backend.cpp): ROW section, " + std::to_string(P.n_row_ops) + " ops\n";
     s += "#include \"device_math.h\"\n\n";
     s += "extern \"C\" __global__ void __launch_bounds__(256) maray_jit_rows(double *__restrict__ yvals, const MarayTex *__restrict__ tex,\n"
-         "                                                                  unsigned y0, unsigned rows, unsigned n_yvals)\n{\n"
+         "                                                                  unsigned y0, unsigned rows, unsigned n_yvals, unsigned w)\n{\n"
          "    const unsigned r = blockIdx.x * 256u + threadIdx.x;\n"
          "    if (r >= rows) return;\n"
-         "    const double Y = (double)(y0 + r);\n"
+         "    const double Y = (double)(y0 + r), XMAX = (double)(w - 1u);\n"
          "    double *yout = yvals + (size_t)r * n_yvals;\n"
-         "    (void)Y; (void)tex; (void)yout;\n";
+         "    (void)Y; (void)XMAX; (void)tex; (void)yout;\n";
     E.section(P.row_ops, P.n_row_ops, P.n_row_slots, false, "r");
-    s += "}\n";
+    s += "}\n\n";
+    // y values [first, first + n_guards) only gate SKIP ops: pack them (value != 0) 32 per word for the pixel kernel
+    s += "extern \"C\" __global__ void __launch_bounds__(256) maray_jit_pack(const double *__restrict__ yvals, unsigned *__restrict__ gwords,\n"
+         "                                                                  unsigned rows, unsigned n_yvals, unsigned first, unsigned n_guards, unsigned n_words)\n{\n"
+         "    const unsigned t = blockIdx.x * 256u + threadIdx.x;\n"
+         "    if (t >= rows * n_words) return;\n"
+         "    const unsigned r = t / n_words, j = t % n_words;\n"
+         "    unsigned wv = 0u;\n"
+         "    for (unsigned b = 0; b < 32u; b++) {\n"
+         "        const unsigned k = 32u * j + b;\n"
+         "        if (k < n_guards && yvals[(size_t)r * n_yvals + first + k] != 0.0) wv |= 1u << b;\n"
+         "    }\n"
+         "    gwords[t] = wv;\n"
+         "}\n";
     return s;
 }
 
@@ -257,9 +304,25 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
     const char *env_ylds = getenv("MARAY_JIT_YLDS");
     const char *env_waves = getenv("MARAY_JIT_WAVES");
     const int min_waves = env_waves ? atoi(env_waves) : min_waves_arg;
-    const bool y_lds = P.n_yvals > 0 && P.n_yvals <= 4096 && !(env_ylds && env_ylds[0] == '0');
+    uint32_t n_ynum = 0;                       // y values read as operands (a prefix of the table); the rest only gate SKIPs
+    for (uint32_t i = 0; i < P.n_pix_ops; i++) {
+        const uint64_t ins = P.pix_ops[i];
+        const uint32_t op = MARAY_INS_OP(ins);
+        if (op == MARAY_OP_NOP || op == MARAY_OP_SKIPZ || op == MARAY_OP_SKIPNZ || op == MARAY_OP_TEXDIM) continue;
+        const uint32_t refs[2] = {MARAY_INS_A(ins), (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) ? MARAY_INS_B(ins) : 0u};
+        for (uint32_t r : refs) if (MARAY_REF_KIND(r) == MARAY_K_YVAL) n_ynum = std::max(n_ynum, MARAY_REF_INDEX(r) + 1);
+    }
+    const bool y_lds = n_ynum > 0 && n_ynum <= 4096 && !(env_ylds && env_ylds[0] == '0');
+    const uint32_t n_guards = P.n_yvals - n_ynum;
+    const uint32_t n_gwords = (n_guards + 31) / 32;
+    // Row-level SKIP ops (guard = a y value) are ignored by default here: measured on chess @4096^2 they halve the
+    // executed ops but hoist ~480 shared values to the top of the kernel, and the register pressure costs more than
+    // the skipped work saves (1.19 ms vs 1.01 ms).  The interpreter kernel takes them (2.8x).  MARAY_JIT_ROW_GUARDS=1
+    // turns them on: the guards then travel as bits, 32 per word, held in SGPRs from the kernel's prologue.
+    E.ignore_row_guards = !jit_row_guards_enabled();
+    if (!E.ignore_row_guards && n_gwords > 0 && n_gwords <= 24) { E.guard_first = n_ynum; E.guard_words = n_gwords; }
     if (y_lds) E.yv_name = "mr_ylds";
-    if (y_lds) s += "__shared__ double mr_ylds[" + std::to_string(P.n_yvals) + "];\n";
+    if (y_lds) s += "__shared__ double mr_ylds[" + std::to_string(n_ynum) + "];\n";
     s += "__shared__ unsigned mr_slow_tile;\n"
          "__device__ inline double mr_defer_sin(double) { mr_slow_tile = 1u; return 0.0; }\n"
          "#define MR_SIN_HUGE(x) mr_defer_sin(x)   // plain Sin ops: flag the tile from the (rare) branch\n"
@@ -269,18 +332,25 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
          ") maray_jit_pixels(unsigned char *__restrict__ rgb8, double *__restrict__ rgb64,\n"
          "                                                                    const double *__restrict__ yvals, const MarayTex *__restrict__ tex,\n"
          "                                                                    unsigned *__restrict__ tile_list, unsigned tile_base,\n"
+         "                                                                    const unsigned *__restrict__ gwords,\n"
          "                                                                    unsigned w, unsigned y0, unsigned n_yvals)\n{\n"
          "    const unsigned x = blockIdx.x * 256u + threadIdx.x;\n"
          "    const unsigned r = blockIdx.y;\n"
          "    if (threadIdx.x == 0) mr_slow_tile = 0u;\n";
     if (y_lds)
-        s += "    for (unsigned i = threadIdx.x; i < " + std::to_string(P.n_yvals) + "u; i += 256u) mr_ylds[i] = yvals[(size_t)r * n_yvals + i];\n";
+        s += "    for (unsigned i = threadIdx.x; i < " + std::to_string(n_ynum) + "u; i += 256u) mr_ylds[i] = yvals[(size_t)r * n_yvals + i];\n";
     s += "    __syncthreads();\n"
          "    const double X = (double)x, Y = (double)(y0 + r);\n"
          "    mr_kptr yv = (mr_kptr)(yvals + (size_t)r * n_yvals);\n"
+         "    const __attribute__((address_space(4))) unsigned *yw = (const __attribute__((address_space(4))) unsigned *)yv;\n"
          "    double o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"
          "    float mr_defer = 0.0f;                     // fused Step(Sin) ops count their undecided cases in here\n"
-         "    (void)X; (void)Y; (void)yv; (void)tex;\n";
+         "    (void)X; (void)Y; (void)yv; (void)yw; (void)tex; (void)gwords;\n";
+    if (E.guard_words) {
+        s += "    const __attribute__((address_space(4))) unsigned *gk = (const __attribute__((address_space(4))) unsigned *)(gwords + (size_t)r * " +
+             std::to_string(E.guard_words) + "u);\n";
+        for (uint32_t j = 0; j < E.guard_words; j++) s += "    const unsigned gw" + std::to_string(j) + " = gk[" + std::to_string(j) + "];\n";
+    }
     E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
     s += "    if (mr_defer != 0.0f && x < w) mr_slow_tile = 1u;\n";
     s += "    if (x < w) {\n"
@@ -346,6 +416,9 @@ struct JitBackend final : Backend {
     hipFunction_t f_rows = nullptr, f_pix = nullptr;
     Backend *slow = nullptr;            // tape interpreter: evaluates the tiles the pixel kernel deferred
     unsigned *d_flags = nullptr; size_t flags_cap = 0;
+    hipFunction_t f_pack = nullptr;
+    unsigned *d_gwords = nullptr; size_t gwords_cap = 0;
+    uint32_t guard_first = 0, n_guards = 0, n_gwords = 0;
     DevTex *d_tex = nullptr;
     std::vector<unsigned char *> d_tex_rgb;
     double *d_yvals = nullptr; size_t yvals_cap = 0;
@@ -360,6 +433,7 @@ struct JitBackend final : Backend {
         if (mod) (void)hipModuleUnload(mod);
         if (mod_rows) (void)hipModuleUnload(mod_rows);
         (void)hipFree(d_flags);
+        (void)hipFree(d_gwords);
         (void)hipFree(d_tex);
         for (auto p : d_tex_rgb) (void)hipFree(p);
         (void)hipFree(d_yvals); (void)hipFree(d_rgb8); (void)hipFree(d_rgb64);
@@ -376,6 +450,20 @@ struct JitBackend final : Backend {
         for (uint32_t i = 0; i < prog.n_pix_ops; i++) {
             const uint32_t op = MARAY_INS_OP(prog.pix_ops[i]);
             if (op == MARAY_OP_SIN || op == MARAY_OP_STEPSIN) has_sin = true;
+        }
+        {   // y values that are only SKIP guards form the tail of the table (see jit_source)
+            uint32_t n_ynum = 0;
+            for (uint32_t i = 0; i < prog.n_pix_ops; i++) {
+                const uint64_t ins = prog.pix_ops[i];
+                const uint32_t op = MARAY_INS_OP(ins);
+                if (op == MARAY_OP_NOP || op == MARAY_OP_SKIPZ || op == MARAY_OP_SKIPNZ || op == MARAY_OP_TEXDIM) continue;
+                const uint32_t refs[2] = {MARAY_INS_A(ins), (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) ? MARAY_INS_B(ins) : 0u};
+                for (uint32_t r : refs) if (MARAY_REF_KIND(r) == MARAY_K_YVAL) n_ynum = std::max(n_ynum, MARAY_REF_INDEX(r) + 1);
+            }
+            guard_first = n_ynum;
+            n_guards = prog.n_yvals - n_ynum;
+            n_gwords = (n_guards + 31) / 32;
+            if (n_gwords > 24 || !jit_row_guards_enabled()) n_gwords = 0;   // not used, or too many for SGPRs (the kernel then reads those y values directly)
         }
         std::vector<char> code, code_rows;
         std::string log;
@@ -400,6 +488,7 @@ struct JitBackend final : Backend {
         if (prog.n_row_ops) {
             HIP_TRY(hipModuleLoadData(&mod_rows, code_rows.data()));
             HIP_TRY(hipModuleGetFunction(&f_rows, mod_rows, "maray_jit_rows"));
+            HIP_TRY(hipModuleGetFunction(&f_pack, mod_rows, "maray_jit_pack"));
         }
         HIP_TRY(hipStreamCreate(&own_stream));
         std::vector<DevTex> descs(n_tex ? n_tex : 1);
@@ -428,11 +517,17 @@ struct JitBackend final : Backend {
         const uint32_t rows_total = y1 - y0;
         if (!rows_total || !w) return;
         ensure(d_yvals, yvals_cap, (size_t)rows_total * std::max<uint32_t>(P.n_yvals, 1));
+        ensure(d_gwords, gwords_cap, (size_t)rows_total * std::max<uint32_t>(n_gwords, 1));
         unsigned n_yvals = P.n_yvals;
         if (rows_pass && P.n_row_ops) {
-            unsigned yy0 = y0, rr = rows_total;
-            void *args[] = {&d_yvals, &d_tex, &yy0, &rr, &n_yvals};
+            unsigned yy0 = y0, rr = rows_total, ww = w;
+            void *args[] = {&d_yvals, &d_tex, &yy0, &rr, &n_yvals, &ww};
             HIP_TRY(hipModuleLaunchKernel(f_rows, (rows_total + 255) / 256, 1, 1, 256, 1, 1, 0, st, args, nullptr));
+            if (n_gwords) {
+                unsigned first = guard_first, ng = n_guards, nw = n_gwords;
+                void *pargs[] = {&d_yvals, &d_gwords, &rr, &n_yvals, &first, &ng, &nw};
+                HIP_TRY(hipModuleLaunchKernel(f_pack, (rows_total * n_gwords + 255) / 256, 1, 1, 256, 1, 1, 0, st, pargs, nullptr));
+            }
         }
         const unsigned gx = (w + 255) / 256;
         const uint64_t n_tiles = (uint64_t)gx * rows_total;
@@ -445,8 +540,9 @@ struct JitBackend final : Backend {
             double *p64 = d64 ? d64 + (size_t)r0 * w * 3 : nullptr;
             const double *yv = d_yvals + (size_t)r0 * n_yvals;
             unsigned *fl = d_flags;
+            const unsigned *gwp = d_gwords + (size_t)r0 * n_gwords;
             unsigned ww = w, yy0 = y0 + r0, tile_base = r0 * gx;
-            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &ww, &yy0, &n_yvals};
+            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &gwp, &ww, &yy0, &n_yvals};
             HIP_TRY(hipModuleLaunchKernel(f_pix, gx, rows, 1, 256, 1, 1, 0, st, args, nullptr));
         }
         if (has_sin) slow->render_flagged(w, y0, y1, d8, d64, st, d_flags, d_yvals);   // no-op unless a tile was deferred

@@ -31,7 +31,7 @@ namespace maray {
 
 namespace {
 
-enum : uint8_t { D_CONST = 100, D_X = 101, D_Y = 102 };   // leaf kinds; ops use MARAY_OP_*
+enum : uint8_t { D_CONST = 100, D_X = 101, D_Y = 102, D_XMAX = 103 };   // leaf kinds; ops use MARAY_OP_*  (XMAX = x of a row's last pixel)
 enum : uint8_t { DEP_X = 1, DEP_Y = 2 };
 
 struct DNode {
@@ -93,7 +93,7 @@ struct Dag {
         if (v != v) v = NAN;   // one canonical NaN
         return intern(DNode{D_CONST, 0, 0, -1, -1, v});
     }
-    int32_t leaf(uint8_t kind) { return intern(DNode{kind, kind == D_X ? DEP_X : DEP_Y, 0, -1, -1, 0.0}); }
+    int32_t leaf(uint8_t kind) { return intern(DNode{kind, (uint8_t)(kind == D_X ? DEP_X : kind == D_Y ? DEP_Y : 0), 0, -1, -1, 0.0}); }
 
     int32_t unary(uint8_t op, int32_t a) {
         if (n[a].op == D_CONST) {
@@ -244,7 +244,7 @@ std::vector<Ival> intervals(const Dag &g)
         Ival r{-INFINITY, INFINITY, true};
         switch (d.op) {
         case D_CONST: r = (d.cval != d.cval) ? Ival{-INFINITY, INFINITY, true} : Ival{d.cval, d.cval, false}; break;
-        case D_X: case D_Y: r = Ival{0.0, dmax, false}; break;
+        case D_X: case D_Y: case D_XMAX: r = Ival{0.0, dmax, false}; break;
         case MARAY_OP_MOV: r = a; break;
         case MARAY_OP_NEG: r = Ival{-a.hi, -a.lo, a.nan}; break;
         case MARAY_OP_ABS:
@@ -280,6 +280,113 @@ std::vector<Ival> intervals(const Dag &g)
 }
 
 // ---- section scheduling + encoding --------------------------------------------------
+// ---- monotonicity in x and row bounds -----------------------------------------------------
+// For a fixed row, is a value a monotone function of the pixel's x *as computed in f64*?  Every
+// rule below composes correctly rounded, NaN-free operations, each of which is monotone in the
+// operand that varies (rounding is monotone), so the property holds for the rounded results and
+// not just for the real-number formula.
+enum Mono : uint8_t { M_CONSTX, M_INC, M_DEC, M_MONO /* monotone, direction depends on the row */, M_NONE };
+
+inline Mono flip(Mono m) { return m == M_INC ? M_DEC : m == M_DEC ? M_INC : m; }
+inline Mono join(Mono a, Mono b)     // both operands vary together (add / min / max)
+{
+    if (a == M_CONSTX) return b;
+    if (b == M_CONSTX) return a;
+    if (a == b && (a == M_INC || a == M_DEC)) return a;
+    return M_NONE;
+}
+
+std::vector<Mono> monotonicity(const Dag &g, const std::vector<Ival> &iv)
+{
+    std::vector<Mono> m(g.n.size(), M_NONE);
+    for (size_t i = 0; i < g.n.size(); i++) {
+        const DNode &d = g.n[i];
+        if (!(d.dep & DEP_X)) { m[i] = M_CONSTX; continue; }
+        if (iv[i].nan) { m[i] = M_NONE; continue; }
+        const Mono a = d.a >= 0 ? m[d.a] : M_NONE, b = d.b >= 0 ? m[d.b] : M_NONE;
+        switch (d.op) {
+        case D_X: m[i] = M_INC; break;
+        case MARAY_OP_MOV: case MARAY_OP_STEP: m[i] = a; break;
+        case MARAY_OP_NEG: m[i] = flip(a); break;
+        case MARAY_OP_SQRT: m[i] = iv[d.a].lo >= 0 ? a : M_NONE; break;
+        case MARAY_OP_ABS: m[i] = iv[d.a].lo >= 0 ? a : (iv[d.a].hi <= 0 ? flip(a) : M_NONE); break;
+        case MARAY_OP_RECIP: m[i] = (iv[d.a].lo > 0 || iv[d.a].hi < 0) ? flip(a) : M_NONE; break;
+        case MARAY_OP_ADD: case MARAY_OP_MIN: case MARAY_OP_MAX: m[i] = join(a, b); break;
+        case MARAY_OP_MUL: {
+            // one factor must be fixed along the row; its sign decides the direction
+            const int32_t v = (b == M_CONSTX) ? d.a : (a == M_CONSTX ? d.b : -1);
+            const int32_t c = (b == M_CONSTX) ? d.b : d.a;
+            if (v < 0 || m[v] == M_NONE) { m[i] = M_NONE; break; }
+            if (iv[c].lo >= 0) m[i] = m[v];
+            else if (iv[c].hi <= 0) m[i] = flip(m[v]);
+            else m[i] = M_MONO;
+            break;
+        }
+        default: m[i] = M_NONE;   // sin / exp / ln (libm monotonicity is not guaranteed), App
+        }
+    }
+    return m;
+}
+
+// Builds, for boolean nodes, y-only boolean expressions that bound them over a whole row:
+//   ub(v)(y) == 0  =>  v(x, y) == 0 for every pixel x in [0, w)        (lb: == 1 => v == 1)
+// A monotone boolean takes its extreme values at the row's end points x = 0 and x = w-1 (XMAX).
+struct RowBounds {
+    Dag &g;
+    const std::vector<uint8_t> &isbool;
+    const std::vector<Mono> &mono;
+    std::unordered_map<uint64_t, int32_t> sub_memo;
+    std::unordered_map<int32_t, std::pair<int32_t, int32_t>> memo;   // node -> (ub, lb)
+    int32_t c_true, c_false, x0, xmax;
+
+    RowBounds(Dag &g_, const std::vector<uint8_t> &b, const std::vector<Mono> &m) : g(g_), isbool(b), mono(m) {
+        c_true = g.konst(1.0); c_false = g.konst(0.0); x0 = g.konst(0.0); xmax = g.leaf(D_XMAX);
+    }
+    int32_t subst(int32_t i, int32_t xr) {          // i with X replaced by node xr
+        const DNode d = g.n[i];
+        if (!(d.dep & DEP_X)) return i;
+        if (d.op == D_X) return xr;
+        const uint64_t key = ((uint64_t)(uint32_t)i << 32) | (uint32_t)xr;
+        auto it = sub_memo.find(key);
+        if (it != sub_memo.end()) return it->second;
+        int32_t r;
+        if (d.b >= 0) {
+            const int32_t a = subst(d.a, xr), b = subst(d.b, xr);
+            r = d.op == MARAY_OP_APP ? g.app(d.aux, a, b) : g.binary(d.op, a, b);
+        } else r = g.unary(d.op, subst(d.a, xr));
+        sub_memo.emplace(key, r);
+        return r;
+    }
+    int32_t b_not(int32_t a) { return g.binary(MARAY_OP_ADD, c_true, g.unary(MARAY_OP_NEG, a)); }
+    std::pair<int32_t, int32_t> bounds(int32_t i) {
+        if ((size_t)i >= isbool.size() || !isbool[i]) return {c_true, c_false};
+        const DNode d = g.n[i];
+        if (!(d.dep & DEP_X)) return {i, i};
+        auto it = memo.find(i);
+        if (it != memo.end()) return it->second;
+        std::pair<int32_t, int32_t> r{c_true, c_false};
+        const Mono m = mono[i];
+        if (m == M_INC || m == M_DEC || m == M_MONO) {
+            const int32_t at0 = subst(i, x0), atw = subst(i, xmax);
+            if (m == M_INC) r = {atw, at0};
+            else if (m == M_DEC) r = {at0, atw};
+            else r = {g.binary(MARAY_OP_MAX, at0, atw), g.binary(MARAY_OP_MIN, at0, atw)};
+        } else if (d.op == MARAY_OP_MUL || d.op == MARAY_OP_MIN) {
+            auto a = bounds(d.a), b = bounds(d.b);
+            r = {g.binary(MARAY_OP_MIN, a.first, b.first), g.binary(MARAY_OP_MIN, a.second, b.second)};
+        } else if (d.op == MARAY_OP_MAX) {
+            auto a = bounds(d.a), b = bounds(d.b);
+            r = {g.binary(MARAY_OP_MAX, a.first, b.first), g.binary(MARAY_OP_MAX, a.second, b.second)};
+        } else if (d.op == MARAY_OP_ADD) {       // 1 + -(b) = NOT b
+            const int32_t nb = g.n[d.a].op == MARAY_OP_NEG ? d.a : d.b;
+            auto a = bounds(g.n[nb].a);
+            r = {b_not(a.second), b_not(a.first)};
+        }
+        memo.emplace(i, r);
+        return r;
+    }
+};
+
 // One scheduled tape op.
 struct SItem {
     int32_t node;          // NODE: the computing node; OUT: the node read; SKIP: the guard
@@ -298,6 +405,7 @@ struct Section {
 };
 
 constexpr size_t MIN_REGION = 6;                // smallest exclusive cone worth a SKIP op
+constexpr size_t MIN_ROW_REGION = 12;           // ... worth a row-level SKIP op (guard = a y value)
 constexpr size_t MAX_REGION = 0x1FFF;           // aux field
 
 struct Lowerer {
@@ -305,6 +413,8 @@ struct Lowerer {
     std::vector<uint8_t> sin_bounded;           // per node: Sin/StepSin argument proven inside reduce_sincos range
     std::vector<uint8_t> isbool;                // per node: value is provably +0.0 or 1.0
     bool regions = true;
+    std::vector<int32_t> rowub;                 // per boolean node: y-only upper bound over a row (DAG node) or -1
+    std::vector<int32_t> used_rowguards;        // row bounds referenced by SKIP ops, in schedule order
     std::vector<uint8_t> in_section;            // node belongs to the section being built
     std::vector<int32_t> need;                  // Sethi-Ullman label
     std::vector<uint8_t> visited;
@@ -312,6 +422,7 @@ struct Lowerer {
     std::unordered_map<uint64_t, uint32_t> const_index;
     std::vector<double> consts;
     std::vector<int32_t> yval_of;               // node -> y value index or -1
+    int row_depth = 0;
 
     explicit Lowerer(const Dag &g_) : g(g_), yval_of(g_.n.size(), -1) {}
 
@@ -343,6 +454,8 @@ struct Lowerer {
         const size_t N = g.n.size();
         need.assign(N, -1);
         visited.assign(N, 0);
+        row_depth = 0;
+        used_rowguards.clear();
         users.assign(N, {});
         for (size_t i = 0; i < N; i++) {
             if (!in_section[i]) continue;
@@ -383,6 +496,19 @@ struct Lowerer {
         return cone;
     }
 
+    // Nodes of r (= reach(v)) that feed nothing but v: they are dead when v's value is known.
+    std::unordered_set<int32_t> self_cone(int32_t v, const std::vector<int32_t> &r) {
+        std::unordered_set<int32_t> cone;
+        for (auto it = r.rbegin(); it != r.rend(); ++it) {
+            const int32_t u0 = *it;
+            if (u0 == v) { cone.insert(v); continue; }
+            bool excl = !users[u0].empty();
+            for (int32_t u : users[u0]) if (u < 0 || !cone.count(u)) { excl = false; break; }
+            if (excl) cone.insert(u0);
+        }
+        return cone;
+    }
+
     int region_kind(int32_t i) const {          // 1: AND (Mul/Min of booleans), 2: OR (Max of booleans)
         const DNode &d = g.n[i];
         if (!isbool[i] || d.a < 0 || d.b < 0 || d.a == d.b || !isbool[d.a] || !isbool[d.b]) return 0;
@@ -393,6 +519,23 @@ struct Lowerer {
 
     void visit(int32_t i, Section &sec) {
         if (i < 0 || visited[i] || !in_section[i]) return;
+        // Row-level short circuit: a y value proves this boolean 0 on the whole row -> skip all that only feeds it.
+        if (regions && !rowub.empty() && rowub[i] >= 0 && row_depth == 0) {      // outermost only: inner ones would mostly be true
+            const std::vector<int32_t> r = reach(i);
+            const std::unordered_set<int32_t> cone = self_cone(i, r);
+            if (cone.size() >= MIN_ROW_REGION && cone.size() <= MAX_REGION / 2) {
+                for (int32_t v : r) if (!cone.count(v)) visit(v, sec);      // shared nodes stay unconditional
+                const size_t mark = sec.sched.size();
+                SItem sk; sk.node = rowub[i]; sk.target = i; sk.nz = 0;
+                sec.sched.push_back(sk);
+                row_depth++;
+                visit(i, sec);                                               // the usual schedule, wave-level regions included
+                row_depth--;
+                if (sec.sched.size() - mark - 1 > MAX_REGION) sec.sched.erase(sec.sched.begin() + (long)mark);
+                else used_rowguards.push_back(rowub[i]);
+                return;
+            }
+        }
         const DNode &d = g.n[i];
         const int kind = regions ? region_kind(i) : 0;
         if (kind) {
@@ -509,6 +652,7 @@ struct Lowerer {
             if (d.op == D_CONST) return MARAY_REF(MARAY_K_CONST, const_ref(d.cval));
             if (d.op == D_X) return MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_X);
             if (d.op == D_Y) return MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_Y);
+            if (d.op == D_XMAX) return MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_XMAX);
             if (in_section[c]) {
                 if (acc_holder[j] == c) { sec.acc_operands++; return MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_ACC); }
                 if (slot[c] < 0) throw Error{MARAY_E_INTERNAL, "operand without a slot"};
@@ -533,7 +677,8 @@ struct Lowerer {
                 const uint32_t a = opref(it.node, j);
                 release(it.node, j);
                 uint32_t dst = MARAY_DST_NONE;
-                if (needs_slot[it.target]) { dst = alloc(); slot[it.target] = (int32_t)dst; }
+                if (slot[it.target] >= 0) dst = (uint32_t)slot[it.target];      // reserved by an enclosing region with the same end
+                else if (needs_slot[it.target]) { dst = alloc(); slot[it.target] = (int32_t)dst; }
                 const uint32_t count = (uint32_t)(item_pos[it.target] - (int32_t)j);
                 sec.ops.push_back(MARAY_INS(it.nz ? MARAY_OP_SKIPNZ : MARAY_OP_SKIPZ, count, dst, a, 0));
                 sec.n_skips++;
@@ -570,6 +715,43 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
     int32_t roots[3];
     for (int c = 0; c < 3; c++) roots[c] = ev.eval(s.color[c], -1);   // outer Context::new() is empty (src/render.rs:53)
 
+    // Boolean typing, intervals, monotonicity on the scene's own DAG; then (optionally) the row bounds,
+    // which append y-only nodes to the DAG, and the typing / intervals once more over the grown DAG.
+    auto bool_typing = [&]() {
+        std::vector<uint8_t> isb(g.n.size(), 0);
+        for (size_t i = 0; i < g.n.size(); i++) {                  // values that are provably +0.0 or 1.0
+            const DNode &d = g.n[i];
+            auto is_one = [&](int32_t c) { return c >= 0 && g.n[c].op == D_CONST && bits_of(g.n[c].cval) == 0x3ff0000000000000ull; };
+            auto is_negbool = [&](int32_t c) { return c >= 0 && g.n[c].op == MARAY_OP_NEG && isb[g.n[c].a]; };
+            switch (d.op) {
+            case D_CONST: isb[i] = bits_of(d.cval) == 0 || bits_of(d.cval) == 0x3ff0000000000000ull; break;
+            case MARAY_OP_STEP: case MARAY_OP_STEPSIN: isb[i] = 1; break;
+            case MARAY_OP_MUL: case MARAY_OP_MIN: case MARAY_OP_MAX: isb[i] = isb[d.a] && isb[d.b]; break;
+            case MARAY_OP_ADD: isb[i] = (is_one(d.a) && is_negbool(d.b)) || (is_one(d.b) && is_negbool(d.a)); break;   // 1 + -(b) = NOT b
+            default: break;
+            }
+        }
+        return isb;
+    };
+    const size_t N0 = g.n.size();
+    const uint32_t folded_scene = g.folded;     // constant ops folded in the scene itself (the row bounds fold more)
+    std::vector<int32_t> rowub;
+    if (opts.no_skips == 0 && opts.hoist_rows != 0 && opts.no_row_guards == 0) {
+        const std::vector<uint8_t> isb0 = bool_typing();
+        const std::vector<Ival> iv0 = intervals(g);
+        const std::vector<Mono> mono0 = monotonicity(g, iv0);
+        RowBounds rb(g, isb0, mono0);
+        rowub.assign(N0, -1);
+        for (size_t i = 0; i < N0; i++) {
+            const uint8_t op = g.n[i].op;
+            // conjunctions only: an OR accumulating many shapes has a bound that is almost always true
+            if (!isb0[i] || !(g.n[i].dep & DEP_X) || !(op == MARAY_OP_MUL || op == MARAY_OP_MIN)) continue;
+            const int32_t ub = rb.bounds((int32_t)i).first;
+            if (g.n[ub].op < D_CONST) rowub[i] = ub;          // a real y-only op (not folded to a constant)
+        }
+        rowub.resize(g.n.size(), -1);
+    }
+
     const size_t N = g.n.size();
     // reachability from the roots
     std::vector<uint8_t> reach(N, 0);
@@ -587,7 +769,7 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
 
     maray_tape_info &info = t.info;
     memset(&info, 0, sizeof info);
-    info.folded_ops = g.folded;
+    info.folded_ops = folded_scene;
     uint32_t max_app = 0;
     for (size_t i = 0; i < N; i++) {
         if (!reach[i]) continue;
@@ -607,19 +789,8 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
 
     Lowerer L(g);
     L.regions = opts.no_skips == 0;
-    L.isbool.assign(N, 0);
-    for (size_t i = 0; i < N; i++) {                  // values that are provably +0.0 or 1.0
-        const DNode &d = g.n[i];
-        auto is_one = [&](int32_t c) { return c >= 0 && g.n[c].op == D_CONST && bits_of(g.n[c].cval) == 0x3ff0000000000000ull; };
-        auto is_negbool = [&](int32_t c) { return c >= 0 && g.n[c].op == MARAY_OP_NEG && L.isbool[g.n[c].a]; };
-        switch (d.op) {
-        case D_CONST: L.isbool[i] = bits_of(d.cval) == 0 || bits_of(d.cval) == 0x3ff0000000000000ull; break;
-        case MARAY_OP_STEP: case MARAY_OP_STEPSIN: L.isbool[i] = 1; break;
-        case MARAY_OP_MUL: case MARAY_OP_MIN: case MARAY_OP_MAX: L.isbool[i] = L.isbool[d.a] && L.isbool[d.b]; break;
-        case MARAY_OP_ADD: L.isbool[i] = (is_one(d.a) && is_negbool(d.b)) || (is_one(d.b) && is_negbool(d.a)); break;   // 1 + -(b) = NOT b
-        default: break;
-        }
-    }
+    L.isbool = bool_typing();
+    L.rowub = rowub;
     {
         const std::vector<Ival> iv = intervals(g);
         L.sin_bounded.assign(N, 0);
@@ -653,12 +824,28 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         L.in_section = is_pix0;
         L.prepare(dry);
         for (int c = 0; c < 3; c++) if (is_pix0[roots[c]]) L.visit(roots[c], dry);
+        // Row bounds the schedule decided to use: they (and what they are computed from) join the ROW
+        // section, and each becomes a y value.
+        for (int32_t rg : L.used_rowguards) {
+            std::vector<int32_t> st{rg};
+            while (!st.empty()) {
+                const int32_t v = st.back(); st.pop_back();
+                if (v < 0 || (reach[v] && (is_row[v] || !is_op(v)))) continue;
+                reach[v] = 1;
+                if (is_op(v)) is_row[v] = 1;
+                st.push_back(g.n[v].a); st.push_back(g.n[v].b);
+            }
+            frontier[rg] = 1;
+        }
         uint32_t k = 0;
         auto number = [&](int32_t c) {
             if (c >= 0 && frontier[c] && L.yval_of[c] < 0) { L.yval_of[c] = (int32_t)k; row.outs.push_back({c, k}); k++; }
         };
+        // arithmetic operands first (the specialised kernel stages exactly this prefix in LDS) ...
         for (const SItem &it : dry.sched) if (it.target < 0) { number(g.n[it.node].a); number(g.n[it.node].b); }
         for (int c = 0; c < 3; c++) number(roots[c]);
+        // ... then the y values that are only ever SKIP guards (row bounds): read as scalars
+        for (const SItem &it : dry.sched) if (it.target >= 0) number(it.node);
         for (size_t i = 0; i < N; i++) number((int32_t)i);
         info.n_yvals = k;
         if (k > MARAY_MAX_INDEX + 1) throw Error{MARAY_E_LIMIT, "more than 16384 row values"};

@@ -33,6 +33,18 @@ def _expr(rng, depth, vars_, n_tex):
         a = step(_expr(rng, depth - 1, vars_, n_tex)); b = step(_expr(rng, depth - 1, vars_, n_tex))
         c = rng.choice([min_, max_, mul])(a, rng.choice([b, sub(nat(1), b)]))
         return c if rng.random() < 0.5 else mul(c, _expr(rng, depth - 2, vars_, n_tex))
+    if r < 0.885:   # half-plane polygons gating a heavier cone: what the row bounds and SKIP regions target
+        def half_plane():
+            a, b, c = rng.choice([1, 2, 3, 7]), rng.choice([0, 1, 2, 5]), rng.randrange(0, 200)
+            e_ = sub(add(mul(x(), nat(a)), mul(y(), nat(b))), nat(c))
+            e_ = mul(e_, div(nat(1), nat(rng.choice([1, 3, 16]))))
+            return step(e_ if rng.random() < 0.5 else neg(e_))
+        poly = min_(min_(half_plane(), half_plane()), half_plane())
+        heavy = _expr(rng, depth - 1, vars_, n_tex)
+        for _ in range(3):
+            heavy = add(mul(heavy, heavy), sin(add(heavy, x())))
+        body = step(heavy) if rng.random() < 0.5 else heavy
+        return rng.choice([mul, min_])(poly, body) if body[0] == 'Step' else mul(poly, body)
     if r < 0.90 and n_tex:
         t = rng.randrange(n_tex)
         sel = rng.choice([channel(t, 0), channel(t, 1), channel(t, 2), image_width(t), image_height(t)])

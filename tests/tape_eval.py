@@ -59,7 +59,7 @@ def _cast_u32(v):
     return np.minimum(v, 4294967295.0).astype(np.uint64)
 
 
-def run_section(ops, consts, n_slots, X, Y, yvals, textures, n_out, honor_skips=False):
+def run_section(ops, consts, n_slots, X, Y, yvals, textures, n_out, honor_skips=False, w=None):
     """Evaluate one section for a vector of items.  X, Y: float64 arrays (same
     shape); yvals: array [..., n_yvals] broadcastable per item or None.
     honor_skips: take SKIPZ / SKIPNZ when the whole vector agrees (call per 64-item "wavefront")."""
@@ -73,7 +73,7 @@ def run_section(ops, consts, n_slots, X, Y, yvals, textures, n_out, honor_skips=
         if kind == K_SLOT: return slots[idx]
         if kind == K_CONST: return np.full(shape, consts[idx])
         if kind == K_YVAL: return yvals[..., idx]
-        return X if idx == 0 else (Y if idx == 1 else acc)
+        return X if idx == 0 else (Y if idx == 1 else (acc if idx == 2 else np.full(shape, float(w - 1))))
 
     with np.errstate(all='ignore'):
         pc = -1
@@ -138,7 +138,7 @@ def render_rows_waves(tape, w, y0, y1, textures=None):
         yv_all = np.zeros((rows, info['n_yvals']))
         for r0 in range(0, rows, 64):
             ys = np.arange(y0 + r0, min(y1, y0 + r0 + 64), dtype=np.float64)
-            outs = run_section(row_ops, consts, info['n_row_slots'], None, ys, None, textures, info['n_yvals'], True)
+            outs = run_section(row_ops, consts, info['n_row_slots'], None, ys, None, textures, info['n_yvals'], True, w=w)
             yv_all[r0:r0 + len(ys)] = np.stack(outs, axis=-1)
     for r in range(rows):
         for x0 in range(0, w, 64):
@@ -159,7 +159,7 @@ def render_rows(tape, w, y0, y1, textures=None):
     ys = np.arange(y0, y1, dtype=np.float64)
     yv = None
     if info['n_yvals']:
-        outs = run_section(row_ops, consts, info['n_row_slots'], None, ys, None, textures, info['n_yvals'])
+        outs = run_section(row_ops, consts, info['n_row_slots'], None, ys, None, textures, info['n_yvals'], w=w)
         yv = np.stack(outs, axis=-1)                       # (rows, n_yvals)
         yv = np.broadcast_to(yv[:, None, :], (rows, w, info['n_yvals']))
     X = np.broadcast_to(np.arange(w, dtype=np.float64)[None, :], (rows, w)).copy()

@@ -70,24 +70,28 @@ def test_fix_color_matches_oracle(chess_bytes):
 
 
 def test_chess_tape_census(chess_bytes):
-    info = M.Scene(chess_bytes).lower().info
+    plain = M.Scene(chess_bytes).lower(skips=False).info      # no skip regions, no row bounds: the bare DAG
     # 535 constant ops folded on the host; Y-only ops hoisted
-    assert info['folded_ops'] == 535
-    assert info['alg_ops'] == info['alg_ops_xy'] + info['alg_ops_x'] + info['alg_ops_y'] + info['alg_ops_uniform']
-    fused = info['op_histogram'][tape_eval.OP['STEPSIN']]
+    assert plain['folded_ops'] == 535
+    assert plain['alg_ops'] == plain['alg_ops_xy'] + plain['alg_ops_x'] + plain['alg_ops_y'] + plain['alg_ops_uniform']
+    fused = plain['op_histogram'][tape_eval.OP['STEPSIN']]
     assert fused == 256                       # every Sin of chess feeds a Step (SURVEY.md finding 4)
-    assert info['n_pix_ops'] == info['alg_ops_xy'] + info['alg_ops_x'] + 3 - fused + info['skip_ops']   # a fused op stands for two
-    assert info['n_row_ops'] == info['alg_ops_y'] + info['n_yvals']
-    assert M.Scene(chess_bytes).lower(skips=False).info['n_pix_slots'] <= 32   # Sethi-Ullman order keeps few values live
-    assert info['n_pix_slots'] <= 96            # hoisting shared nodes out of skip regions costs some
-    assert info['op_histogram'][tape_eval.OP['SIN']] == 0
-    unfused = M.Scene(chess_bytes).lower(fuse=False).info
-    assert unfused['op_histogram'][tape_eval.OP['SIN']] == 256 and unfused['alg_ops'] == info['alg_ops']
-    assert info['sin_ops'] == info['sin_bounded'] == 256      # interval analysis: |arg| < 105414350 everywhere
-    assert info['op_histogram'][tape_eval.OP['OUT']] == 3
-    plain = M.Scene(chess_bytes).lower(plain_cse=True).info
-    assert plain['alg_ops_y'] == 844            # Y-only census of SURVEY.md §8(d)
-    assert plain['alg_ops'] >= info['alg_ops']
+    assert plain['n_pix_ops'] == plain['alg_ops_xy'] + plain['alg_ops_x'] + 3 - fused   # a fused op stands for two
+    assert plain['n_row_ops'] == plain['alg_ops_y'] + plain['n_yvals']
+    assert plain['n_pix_slots'] <= 32         # Sethi-Ullman order keeps few values live
+    assert plain['op_histogram'][tape_eval.OP['SIN']] == 0 and plain['op_histogram'][tape_eval.OP['OUT']] == 3
+    unfused = M.Scene(chess_bytes).lower(fuse=False, skips=False).info
+    assert unfused['op_histogram'][tape_eval.OP['SIN']] == 256 and unfused['alg_ops'] == plain['alg_ops']
+    assert plain['sin_ops'] == plain['sin_bounded'] == 256      # interval analysis: |arg| < 105414350 everywhere
+    # default lowering: same computing ops + SKIP ops; row bounds add y values and ROW work
+    info = M.Scene(chess_bytes).lower().info
+    assert info['folded_ops'] == 535 and info['alg_ops'] == plain['alg_ops']
+    assert info['n_pix_ops'] == plain['n_pix_ops'] + info['skip_ops']
+    assert info['skip_ops'] > 800 and info['n_yvals'] > plain['n_yvals'] and info['n_row_ops'] > plain['n_row_ops']
+    assert info['n_pix_slots'] <= 96          # hoisting shared nodes out of skip regions costs some
+    nocommute = M.Scene(chess_bytes).lower(plain_cse=True, skips=False).info
+    assert nocommute['alg_ops_y'] == 844      # Y-only census of SURVEY.md §8(d)
+    assert nocommute['alg_ops'] >= plain['alg_ops']
 
 
 @pytest.mark.parametrize('hoist', [True, False])
