@@ -39,6 +39,30 @@ namespace maray {
 
 namespace {
 
+// Number of leading y values that PIXEL ops read as arithmetic operands; the rest of the table only gates SKIP ops.
+uint32_t numeric_yvals(const maray_program &P)
+{
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < P.n_pix_ops; i++) {
+        const uint64_t ins = P.pix_ops[i];
+        const uint32_t op = MARAY_INS_OP(ins);
+        if (op == MARAY_OP_NOP || op == MARAY_OP_SKIPZ || op == MARAY_OP_SKIPNZ || op == MARAY_OP_TEXDIM) continue;
+        const uint32_t refs[2] = {MARAY_INS_A(ins), (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) ? MARAY_INS_B(ins) : 0u};
+        for (uint32_t r : refs) if (MARAY_REF_KIND(r) == MARAY_K_YVAL) n = std::max(n, MARAY_REF_INDEX(r) + 1);
+    }
+    return n;
+}
+
+// Can the pixel kernel defer tiles to the interpreter?  Only a Sin / Step(Sin) whose argument is not proven bounded can.
+bool may_defer_tiles(const maray_program &P)
+{
+    for (uint32_t i = 0; i < P.n_pix_ops; i++) {
+        const uint32_t op = MARAY_INS_OP(P.pix_ops[i]);
+        if ((op == MARAY_OP_SIN || op == MARAY_OP_STEPSIN) && !(MARAY_INS_AUX(P.pix_ops[i]) & MARAY_AUX_SIN_BOUNDED)) return true;
+    }
+    return false;
+}
+
 bool jit_row_guards_enabled()
 {
     const char *e_ = getenv("MARAY_JIT_ROW_GUARDS");
@@ -73,6 +97,7 @@ struct Emitter {
     std::vector<Val> vals;   // one per op of the current section
     std::string yv_name = "yv";
     bool ignore_row_guards = false;
+    uint32_t row_out_limit = 0xFFFFFFFFu;        // ROW kernel: y values >= this are not produced
     uint32_t guard_first = 0, guard_words = 0;   // y values >= guard_first are SKIP guards packed as bits (32 per word)
     explicit Emitter(const maray_program &p) : P(p) {}
 
@@ -159,6 +184,7 @@ struct Emitter {
                 continue;
             }
             if (op == MARAY_OP_OUT) {
+                if (!pixel && aux >= row_out_limit) continue;    // a guard the pixel kernel ignores: its cone is dead code
                 const std::string a = dbl(va, "m", i, 0);
                 out += pixel ? "    o" + std::to_string(aux) + " = " + a + ";\n"
                              : "    yout[" + std::to_string(aux) + "] = " + a + ";\n";
@@ -257,6 +283,8 @@ std::string jit_source_rows(const maray_program &P)
 {
     validate_program(P);
     Emitter E(P);
+    // the interpreter (which drains deferred tiles from the same y-value table) does read the guard values
+    if (!jit_row_guards_enabled() && !may_defer_tiles(P)) E.row_out_limit = numeric_yvals(P);
     std::string &s = E.out;
     s += "// generated by libmaray_hip (jit_backend.cpp): ROW section, " + std::to_string(P.n_row_ops) + " ops\n";
     s += "#include \"device_math.h\"\n\n";
@@ -304,14 +332,7 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
     const char *env_ylds = getenv("MARAY_JIT_YLDS");
     const char *env_waves = getenv("MARAY_JIT_WAVES");
     const int min_waves = env_waves ? atoi(env_waves) : min_waves_arg;
-    uint32_t n_ynum = 0;                       // y values read as operands (a prefix of the table); the rest only gate SKIPs
-    for (uint32_t i = 0; i < P.n_pix_ops; i++) {
-        const uint64_t ins = P.pix_ops[i];
-        const uint32_t op = MARAY_INS_OP(ins);
-        if (op == MARAY_OP_NOP || op == MARAY_OP_SKIPZ || op == MARAY_OP_SKIPNZ || op == MARAY_OP_TEXDIM) continue;
-        const uint32_t refs[2] = {MARAY_INS_A(ins), (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) ? MARAY_INS_B(ins) : 0u};
-        for (uint32_t r : refs) if (MARAY_REF_KIND(r) == MARAY_K_YVAL) n_ynum = std::max(n_ynum, MARAY_REF_INDEX(r) + 1);
-    }
+    const uint32_t n_ynum = numeric_yvals(P);   // y values read as operands (a prefix of the table); the rest only gate SKIPs
     const bool y_lds = n_ynum > 0 && n_ynum <= 4096 && !(env_ylds && env_ylds[0] == '0');
     const uint32_t n_guards = P.n_yvals - n_ynum;
     const uint32_t n_gwords = (n_guards + 31) / 32;
@@ -425,7 +446,7 @@ struct JitBackend final : Backend {
     unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;
     double *d_rgb64 = nullptr; size_t rgb64_cap = 0;
     hipStream_t own_stream = nullptr;
-    bool has_sin = false;
+    bool has_sin = false;               // some Sin argument is not proven bounded: tiles may be deferred to `slow`
 
     ~JitBackend() override {
         (void)hipSetDevice(device);
@@ -447,19 +468,9 @@ struct JitBackend final : Backend {
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
             throw Error{MARAY_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only"};
-        for (uint32_t i = 0; i < prog.n_pix_ops; i++) {
-            const uint32_t op = MARAY_INS_OP(prog.pix_ops[i]);
-            if (op == MARAY_OP_SIN || op == MARAY_OP_STEPSIN) has_sin = true;
-        }
+        has_sin = may_defer_tiles(prog);
         {   // y values that are only SKIP guards form the tail of the table (see jit_source)
-            uint32_t n_ynum = 0;
-            for (uint32_t i = 0; i < prog.n_pix_ops; i++) {
-                const uint64_t ins = prog.pix_ops[i];
-                const uint32_t op = MARAY_INS_OP(ins);
-                if (op == MARAY_OP_NOP || op == MARAY_OP_SKIPZ || op == MARAY_OP_SKIPNZ || op == MARAY_OP_TEXDIM) continue;
-                const uint32_t refs[2] = {MARAY_INS_A(ins), (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) ? MARAY_INS_B(ins) : 0u};
-                for (uint32_t r : refs) if (MARAY_REF_KIND(r) == MARAY_K_YVAL) n_ynum = std::max(n_ynum, MARAY_REF_INDEX(r) + 1);
-            }
+            const uint32_t n_ynum = numeric_yvals(prog);
             guard_first = n_ynum;
             n_guards = prog.n_yvals - n_ynum;
             n_gwords = (n_guards + 31) / 32;
@@ -467,19 +478,18 @@ struct JitBackend final : Backend {
         }
         std::vector<char> code, code_rows;
         std::string log;
-        // Occupancy: ask for 8 waves per SIMD (<= 64 VGPRs; chess @4096^2: 1.02 ms vs 1.13 ms at 4); if that
-        // costs more than a few spill slots, rebuild for 4 waves per SIMD (<= 128 VGPRs).
-        jit_compile(jit_source(prog, 8), code, log);
-        HIP_TRY(hipModuleLoadData(&mod, code.data()));
-        HIP_TRY(hipModuleGetFunction(&f_pix, mod, "maray_jit_pixels"));
-        int scratch = 0;
-        HIP_TRY(hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f_pix));
-        if (scratch > 256 && !getenv("MARAY_JIT_WAVES")) {
-            (void)hipModuleUnload(mod);
-            mod = nullptr;
-            jit_compile(jit_source(prog, 4), code, log);
+        // Occupancy: the highest of 8 / 6 / 4 waves per SIMD (<= 64 / 80 / 128 VGPRs) whose build needs no scratch:
+        // spilled VGPRs are HBM traffic (chess @4096^2 at 8 waves: 44 B per work-item = 0.6 GB per launch for 4 %
+        // more speed; MARAY_JIT_WAVES=8 asks for that build).
+        const int ladder[] = {8, 6, 4};
+        for (int k = 0; k < 3; k++) {
+            if (mod) { (void)hipModuleUnload(mod); mod = nullptr; }
+            jit_compile(jit_source(prog, ladder[k]), code, log);
             HIP_TRY(hipModuleLoadData(&mod, code.data()));
             HIP_TRY(hipModuleGetFunction(&f_pix, mod, "maray_jit_pixels"));
+            int scratch = 0;
+            HIP_TRY(hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f_pix));
+            if (scratch == 0 || getenv("MARAY_JIT_WAVES")) break;
         }
         if (prog.n_row_ops) jit_compile(jit_source_rows(prog), code_rows, log);
         slow = make_tape_backend(dev, prog, tex, n_tex, false);
@@ -533,7 +543,7 @@ struct JitBackend final : Backend {
         const uint64_t n_tiles = (uint64_t)gx * rows_total;
         if (n_tiles > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
         ensure(d_flags, flags_cap, (size_t)n_tiles + 1);                    // work list {count, tile, ...} of deferred tiles
-        HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(unsigned), st));
+        if (has_sin) HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(unsigned), st));
         for (uint32_t r0 = 0; r0 < rows_total; r0 += 65535) {          // gridDim.y limit
             const uint32_t rows = std::min<uint32_t>(65535, rows_total - r0);
             unsigned char *p8 = d8 ? d8 + (size_t)r0 * w * 3 : nullptr;
