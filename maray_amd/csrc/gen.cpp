@@ -5,9 +5,9 @@
 //   ReportState        <- Report::start / Report::update   src/report.rs:26-56
 //
 // Multi-GPU: pixels are independent (src/render.rs:85), so the image is cut
-// into contiguous row ranges, one per device, each rendered by its own context
-// on its own host thread straight into the caller's raster (host-side gather,
-// no collective).  The progress callback runs on the calling thread.
+// into row tiles dealt round-robin to the devices, each rendered by its own
+// context on its own host thread straight into the caller's raster (host-side
+// gather, no collective).  The progress callback runs on the calling thread.
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -92,10 +92,12 @@ extern "C" int maray_gen_to_image(const maray_scene *s, const maray_texture *tex
     }
 
     Progress P;
+    // Row tiles are dealt to the devices round-robin: the cost of a row depends on what it shows (the
+    // kernels skip work wave by wave), so contiguous bands would leave the device with the busiest band behind.
     auto worker = [&](uint32_t d) {
-        const uint32_t ya = (uint32_t)((uint64_t)h * d / n_dev), yb = (uint32_t)((uint64_t)h * (d + 1) / n_dev);
-        for (uint32_t y = ya; y < yb; y += tile_rows) {
-            const uint32_t y1 = std::min(yb, y + tile_rows);
+        for (uint64_t y64 = (uint64_t)d * tile_rows; y64 < h; y64 += (uint64_t)n_dev * tile_rows) {
+            const uint32_t y = (uint32_t)y64;
+            const uint32_t y1 = (uint32_t)std::min<uint64_t>(h, y64 + tile_rows);
             int r = maray_hip_render_rows(ctxs[d], w, h, y, y1, rgb8 + (size_t)y * w * 3, nullptr);
             std::lock_guard<std::mutex> lk(P.m);
             if (r) { P.failed = r; P.err = Error{r, maray_last_error()}; P.cv.notify_all(); return; }

@@ -1,0 +1,58 @@
+// lower_asan.cpp — host-only sanitizer harness for the product's reader, fix_color and lowering
+// (test infrastructure).  Built with -fsanitize=address,undefined together with scene.cpp and lower.cpp;
+// reads .maray files given on the command line, lowers each with several option sets and validates the
+// resulting programs structurally.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "expr.hpp"
+#include "lower.hpp"
+
+using namespace maray;
+
+namespace maray { void validate_program(const maray_program &p); }
+
+static std::vector<uint8_t> slurp(const char *path)
+{
+    std::vector<uint8_t> b;
+    FILE *f = fopen(path, "rb");
+    if (!f) return b;
+    uint8_t tmp[65536];
+    size_t n;
+    while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) b.insert(b.end(), tmp, tmp + n);
+    fclose(f);
+    return b;
+}
+
+int main(int argc, char **argv)
+{
+    int lowered = 0, rejected = 0;
+    for (int i = 1; i < argc; i++) {
+        std::vector<uint8_t> bytes = slurp(argv[i]);
+        // also feed every truncation point class: the reader must fail cleanly, never read out of bounds
+        for (size_t cut : {bytes.size(), bytes.size() / 2, (size_t)9, (size_t)3}) {
+            if (cut > bytes.size()) continue;
+            Scene s;
+            try { scene_decode(bytes.data(), cut, s); }
+            catch (const Error &) { rejected++; continue; }
+            std::vector<uint8_t> again;
+            scene_encode(s, again);
+            for (int variant = 0; variant < 4; variant++) {
+                maray_lower_opts o;
+                memset(&o, 0, sizeof o);
+                o.hoist_rows = variant != 1;
+                o.no_skips = variant == 2;
+                o.no_row_guards = variant == 3;
+                Tape t;
+                try { lower_scene(s, o, t); }
+                catch (const Error &e) { if (e.code != MARAY_E_ALIASED && e.code != MARAY_E_CYCLE) { fprintf(stderr, "%s: %s\n", argv[i], e.msg.c_str()); return 1; } rejected++; continue; }
+                validate_program(t.program());
+                lowered++;
+            }
+        }
+    }
+    printf("lowered %d programs, rejected %d inputs\n", lowered, rejected);
+    return 0;
+}

@@ -211,6 +211,15 @@ def test_many_live_values_spill_path():
     gpu_vs_oracle(data, 512, 3, [(0, 3)])
 
 
+def test_gen_to_image_with_more_devices_than_present_fails_cleanly(chess_bytes):
+    n = M.device_count()
+    with pytest.raises(M.MarayError):
+        M.gen_to_image(M.Scene(chess_bytes), n_devices=n + 1)
+    img = M.gen_to_image(M.Scene(chess_bytes), n_devices=n, tile_rows=100)      # ragged tile height
+    g = json.load(open(os.path.join(GOLDEN, 'chess_1024.json')))
+    assert hashlib.sha256(img.tobytes()).hexdigest() == g['rgb8_sha256']
+
+
 def test_gen_to_image_and_png_roundtrip(tmp_path, chess_bytes):
     s = M.Scene(chess_bytes)
     seen = []
