@@ -82,6 +82,7 @@ def main():
         except M.MarayError as e:
             if args.backend != 'auto':
                 raise
+            print('bench.py: backend %s unavailable (%s); trying the next one' % (name, e), file=sys.stderr, flush=True)
             last = e
     if ctx is None:
         raise last

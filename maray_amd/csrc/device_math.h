@@ -9,6 +9,24 @@
 
 #define MARAY_DEV __device__ __forceinline__
 
+// Booleans of the specialised kernels: one bit per lane of the wavefront, held in an SGPR pair.
+typedef unsigned long long mr_mask;
+#define MR_ALL (~0ull)
+#define MR_NONE 0ull
+#define mr_ballot(c) __builtin_amdgcn_ballot_w64(c)            /* per-lane condition -> mask (v_cmp writes it) */
+
+// mask -> the f64 it stands for, per lane: {hi, 0} with hi = m[lane] ? on : off, one v_cndmask_b32 that reads the
+// mask straight from its SGPR pair.  (Inline asm rather than __builtin_amdgcn_inverse_ballot_w64: a process
+// that imported PyTorch first compiles with PyTorch's bundled ROCm 7.0 hiprtc, which lacks that builtin.)
+MARAY_DEV double mr_mask_f64(mr_mask m, unsigned on, unsigned off)
+{
+    unsigned hi;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(off), "v"(on), "s"(m));
+    return __builtin_bit_cast(double, (unsigned long long)hi << 32);
+}
+#define mr_pos(m) mr_mask_f64(m, 0x3ff00000u, 0u)              /* +1.0 : +0.0 */
+#define mr_neg01(m) mr_mask_f64(m, 0xbff00000u, 0x80000000u)   /* -1.0 : -0.0 */
+
 // Neg Abs Recip Sqrt: IEEE-754 exact (:640-643).  1.0/a and sqrt lower to the
 // correctly rounded f64 expansions (no fast-math).
 MARAY_DEV double mr_neg(double a) { return -a; }

@@ -65,8 +65,8 @@ bool may_defer_tiles(const maray_program &P)
 
 bool jit_row_guards_enabled()
 {
-    const char *e_ = getenv("MARAY_JIT_ROW_GUARDS");
-    return e_ && e_[0] == '1';
+    const char *e_ = getenv("MARAY_JIT_ROW_GUARDS");      // "0": compile the row-level SKIP ops away (ablation)
+    return !(e_ && e_[0] == '0');
 }
 
 std::string lit(double v)
@@ -79,18 +79,23 @@ std::string lit(double v)
 }
 
 // Values whose every possible result is exactly +0.0 or 1.0 ("booleans": Step, Step(Sin), and
-// Mul / Min / Max / `1 + Neg(.)` of booleans) are carried as C++ `bool`s, i.e. wave lane masks that
-// the compiler combines with scalar s_and / s_or / s_andn2 instead of v_mul_f64 / v_min_f64 /
-// v_max_f64 + v_cndmask.  Exact, because on {+0.0, 1.0}: a*b = min(a,b) = a AND b, max(a,b) = a OR b,
-// 1 + (-a) = NOT a (1 + -1 = +0, 1 + -0 = 1) — all results are again +0.0 or 1.0, never -0.0.
-// About half of chess.maray's ops are of this kind.  The f64 value is materialised
-// (b ? 1.0 : 0.0) only where a non-boolean op consumes it.
+// Mul / Min / Max / `1 + Neg(.)` of booleans) are carried as 64-bit wave lane masks (`mr_mask`, one
+// bit per lane, the result of a ballot): wave-uniform integers that live in SGPR pairs and are
+// combined by s_and_b64 / s_or_b64 / s_not_b64 instead of v_mul_f64 / v_min_f64 / v_max_f64 +
+// v_cndmask, and tested by s_cmp_*_u64.  Exact, because on {+0.0, 1.0}: a*b = min(a,b) = a AND b,
+// max(a,b) = a OR b, 1 + (-a) = NOT a (1 + -1 = +0, 1 + -0 = 1) — all results are again +0.0 or
+// 1.0, never -0.0.  About half of chess.maray's ops are of this kind.  The f64 value is
+// materialised (mr_pos(m), one v_cndmask_b32 on the mask) only where a non-boolean op
+// consumes it.  Explicit masks rather than C++ `bool`s: LLVM keeps an i1 that crosses a basic
+// block (every region result does) as a 0/1 VGPR and re-derives the mask with v_cmp, three VALU
+// ops per region on the path that skips it.  Bits of lanes that are not executing are garbage
+// (NOT sets them); they can only make a region run that could have been skipped.
 struct Emitter {
-    enum Kind { DBL, BOOL, NEGBOOL };   // NEGBOOL: value is -(b) in {-0.0, -1.0}, b = the named bool
+    enum Kind { DBL, BOOL, NEGBOOL };   // NEGBOOL: value is -(b) in {-0.0, -1.0}, b = the named mask
     struct Val {
         Kind kind = DBL;
         std::string d;   // name / literal of the double, empty until materialised
-        std::string b;   // name / literal of the bool (BOOL, NEGBOOL)
+        std::string b;   // name / literal of the lane mask (BOOL, NEGBOOL)
     };
     const maray_program &P;
     std::string out;
@@ -99,11 +104,14 @@ struct Emitter {
     bool ignore_row_guards = false;
     uint32_t row_out_limit = 0xFFFFFFFFu;        // ROW kernel: y values >= this are not produced
     uint32_t guard_first = 0, guard_words = 0;   // y values >= guard_first are SKIP guards packed as bits (32 per word)
+    std::vector<uint8_t> is_bool_op;             // out: per op of the last section(), was its value carried as a bool
+    std::vector<uint8_t> bool_hint;              // in: the same from a dry run without row guards (types their regions)
     explicit Emitter(const maray_program &p) : P(p) {}
 
     void section(const uint64_t *ops, uint32_t n, uint32_t n_slots, bool pixel, const char *prefix)
     {
         vals.assign(n, Val());
+        is_bool_op.assign(n, 0);
         std::vector<int> slot(n_slots, -1);
         int acc = -1;
         char name[48];
@@ -120,8 +128,8 @@ struct Emitter {
                 const double c = P.consts[idx];
                 t.d = lit(c);
                 uint64_t bits; memcpy(&bits, &c, 8);
-                if (bits == 0x3ff0000000000000ull) { t.kind = BOOL; t.b = "true"; }
-                else if (bits == 0) { t.kind = BOOL; t.b = "false"; }
+                if (bits == 0x3ff0000000000000ull) { t.kind = BOOL; t.b = "MR_ALL"; }
+                else if (bits == 0) { t.kind = BOOL; t.b = "MR_NONE"; }
                 return &t;
             }
             case MARAY_K_YVAL: t.d = yv_name + "[" + std::to_string(idx) + "]"; return &t;
@@ -137,7 +145,7 @@ struct Emitter {
             snprintf(name, sizeof name, "%s%u_%c", hint, i, which ? 'b' : 'a');
             out += "    const double ";
             out += name;
-            out += v->kind == BOOL ? " = " + v->b + " ? 1.0 : 0.0;\n" : " = " + v->b + " ? -1.0 : -0.0;\n";
+            out += v->kind == BOOL ? " = mr_pos(" + v->b + ");\n" : " = mr_neg01(" + v->b + ");\n";
             v->d = name;
             return v->d;
         };
@@ -154,10 +162,12 @@ struct Emitter {
                 const bool nz = op == MARAY_OP_SKIPNZ;
                 const uint32_t end = i + aux;
                 snprintf(name, sizeof name, "%s%u", prefix, end);
-                const bool as_bool = va->kind == BOOL;
                 const uint32_t gref = MARAY_INS_A(ins);
                 const bool row_guard = pixel && MARAY_REF_KIND(gref) == MARAY_K_YVAL;
                 if (row_guard && ignore_row_guards) continue;      // legal: an evaluator may ignore any SKIP op
+                // the region's variable is a lane mask when its last op yields one: the guard tells for a wave-level
+                // region (a boolean guards a boolean AND / OR), the dry run for a row-level one (its guard is a y value)
+                const bool as_bool = row_guard ? (end < bool_hint.size() && bool_hint[end]) : va->kind == BOOL;
                 std::string cond;
                 if (row_guard && !nz && guard_words && MARAY_REF_INDEX(gref) >= guard_first) {
                     // a row bound: one bit of a guard word that sits in an SGPR since the kernel's prologue
@@ -168,17 +178,17 @@ struct Emitter {
                     const std::string k = std::to_string(MARAY_REF_INDEX(gref));
                     cond = nz ? "!(yw[2 * " + k + " + 1] == 0x3ff00000u && yw[2 * " + k + "] == 0u)"
                               : "((yw[2 * " + k + " + 1] << 1) | yw[2 * " + k + "]) != 0u";
-                } else if (as_bool) cond = nz ? "!" + va->b : va->b;
-                else cond = "(" + dbl(va, "m", i, 0) + (nz ? " != 1.0)" : " != 0.0)");
+                } else if (as_bool) cond = nz ? "~" + va->b + " != MR_NONE" : va->b + " != MR_NONE";      // a scalar compare
+                else cond = "mr_ballot(" + dbl(va, "m", i, 0) + (nz ? " != 1.0) != MR_NONE" : " != 0.0) != MR_NONE");
                 // several regions may end at one op (a row-level guard around a wave-level one): one variable
                 bool typed_bool = as_bool;
                 bool declared = false;
                 for (const Open &o : open) if (o.end == end) { declared = true; typed_bool = o.as_bool; }
-                if (!declared) out += typed_bool ? "    bool b" + std::string(name) + ";\n" : "    double " + std::string(name) + ";\n";
+                if (!declared) out += typed_bool ? "    mr_mask b" + std::string(name) + ";\n" : "    double " + std::string(name) + ";\n";
                 // regions are entered rarely (chess: 2-20 %): mark them unlikely so that the block placement keeps the
                 // skip path as the fall-through and moves the region bodies out of line (taken jumps stall on instruction fetch)
                 const bool cold = !getenv("MARAY_JIT_NO_EXPECT");
-                const std::string test = row_guard ? cond : "__builtin_amdgcn_ballot_w64(" + cond + ") != 0ull";
+                const std::string &test = cond;
                 out += cold ? "    if (__builtin_expect(" + test + ", 0)) {\n" : "    if (" + test + ") {\n";
                 open.push_back(Open{end, typed_bool, nz});
                 continue;
@@ -203,15 +213,15 @@ struct Emitter {
                 if (va->kind == BOOL) { r.kind = NEGBOOL; r.b = va->b; }
                 else e = "mr_neg(" + dbl(va, "m", i, 0) + ")";
                 break;
-            case MARAY_OP_STEP: be = "(" + dbl(va, "m", i, 0) + " >= 0.0)"; break;
+            case MARAY_OP_STEP: be = "mr_ballot(" + dbl(va, "m", i, 0) + " >= 0.0)"; break;
             case MARAY_OP_STEPSIN:
-                if (aux & MARAY_AUX_SIN_BOUNDED) be = "mr_stepsin_bounded_b(" + dbl(va, "m", i, 0) + ")";
+                if (aux & MARAY_AUX_SIN_BOUNDED) be = "mr_ballot(mr_stepsin_bounded_b(" + dbl(va, "m", i, 0) + "))";
                 else e = pixel ? "mr_stepsin_fast(" + dbl(va, "m", i, 0) + ", &mr_defer)" : "mr_stepsin(" + dbl(va, "m", i, 0) + ")";
                 break;
             case MARAY_OP_ADD:
                 // 1.0 + (-(b)) = NOT b
-                if (va->kind == BOOL && va->b == "true" && vb->kind == NEGBOOL) be = "!" + vb->b;
-                else if (vb->kind == BOOL && vb->b == "true" && va->kind == NEGBOOL) be = "!" + va->b;
+                if (va->kind == BOOL && va->b == "MR_ALL" && vb->kind == NEGBOOL) be = "~" + vb->b;
+                else if (vb->kind == BOOL && vb->b == "MR_ALL" && va->kind == NEGBOOL) be = "~" + va->b;
                 else e = dbl(va, "m", i, 0) + " + " + dbl(vb, "m", i, 1);
                 break;
             case MARAY_OP_MUL:
@@ -244,31 +254,32 @@ struct Emitter {
                 const Open o = open.back();
                 open.pop_back();
                 if (o.as_bool && !be.empty()) {
-                    out += "    b" + self + " = " + be + ";\n    } else b" + self + (o.nz ? " = true;\n" : " = false;\n");
+                    out += "    b" + self + " = " + be + ";\n    } else b" + self + (o.nz ? " = MR_ALL;\n" : " = MR_NONE;\n");
                     r.kind = BOOL; r.b = "b" + self;
                 } else if (o.as_bool) {
                     // guard was boolean but the result is not typed so: keep the double form
-                    out += "    b" + self + " = (" + e + ") != 0.0;\n    } else b" + self + (o.nz ? " = true;\n" : " = false;\n");
+                    out += "    b" + self + " = mr_ballot((" + e + ") != 0.0);\n    } else b" + self + (o.nz ? " = MR_ALL;\n" : " = MR_NONE;\n");
                     r.kind = BOOL; r.b = "b" + self;
                 } else {
-                    const std::string ee = !e.empty() ? e : "(" + be + " ? 1.0 : 0.0)";
+                    const std::string ee = !e.empty() ? e : "mr_pos(" + be + ")";
                     out += "    " + self + " = " + ee + ";\n    } else " + self + (o.nz ? " = 1.0;\n" : " = 0.0;\n");
                     r.kind = DBL; r.d = self;
                 }
                 while (!open.empty() && open.back().end == i) {     // enclosing regions that end here too
                     const Open o2 = open.back();
                     open.pop_back();
-                    out += o.as_bool ? "    } else b" + self + (o2.nz ? " = true;\n" : " = false;\n")
+                    out += o.as_bool ? "    } else b" + self + (o2.nz ? " = MR_ALL;\n" : " = MR_NONE;\n")
                                      : "    } else " + self + (o2.nz ? " = 1.0;\n" : " = 0.0;\n");
                 }
             } else if (!be.empty()) {
-                out += "    const bool b" + self + " = " + be + ";\n";
+                out += "    const mr_mask b" + self + " = " + be + ";\n";
                 r.kind = BOOL; r.b = "b" + self;
             } else if (!e.empty()) {
                 out += "    const double " + self + " = " + e + ";\n";
                 r.kind = DBL; r.d = self;
             }
             vals[i] = r;
+            is_bool_op[i] = r.kind == BOOL;
             acc = (int)i;
             if (dst != MARAY_DST_NONE) slot[dst] = (int)i;
         }
@@ -371,6 +382,13 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
         s += "    const __attribute__((address_space(4))) unsigned *gk = (const __attribute__((address_space(4))) unsigned *)(gwords + (size_t)r * " +
              std::to_string(E.guard_words) + "u);\n";
         for (uint32_t j = 0; j < E.guard_words; j++) s += "    const unsigned gw" + std::to_string(j) + " = gk[" + std::to_string(j) + "];\n";
+    }
+    if (!E.ignore_row_guards) {         // dry run: which ops yield lane masks
+        Emitter D(P);
+        D.yv_name = E.yv_name;
+        D.ignore_row_guards = true;
+        D.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+        E.bool_hint = D.is_bool_op;
     }
     E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
     s += "    if (mr_defer != 0.0f && x < w) mr_slow_tile = 1u;\n";

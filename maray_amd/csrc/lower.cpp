@@ -40,6 +40,7 @@ struct DNode {
     uint32_t aux;
     int32_t a, b;
     double cval;
+    uint32_t inst = 0;     // 0 = shared (hash-consed); k > 0 = private copy owned by row region k
 };
 
 inline uint64_t bits_of(double v) { uint64_t u; memcpy(&u, &v, 8); return u; }
@@ -80,7 +81,7 @@ struct Dag {
     bool fuse = true;
 
     int32_t intern(const DNode &d) {
-        std::array<uint64_t, 3> k = {(uint64_t)d.op | ((uint64_t)d.aux << 8), ((uint64_t)(uint32_t)d.a << 32) | (uint32_t)d.b,
+        std::array<uint64_t, 3> k = {(uint64_t)d.op | ((uint64_t)d.aux << 8) | ((uint64_t)d.inst << 32), ((uint64_t)(uint32_t)d.a << 32) | (uint32_t)d.b,
                                      d.op == D_CONST ? bits_of(d.cval) : 0};
         auto it = map.find(k);
         if (it != map.end()) return it->second;
@@ -387,6 +388,82 @@ struct RowBounds {
     }
 };
 
+
+constexpr size_t MIN_ROW_REGION = 12;           // smallest region worth a row-level SKIP op (guard = a y value)
+constexpr size_t MAX_REGION = 0x1FFF;           // aux field
+
+// Gives every row region its own copy of the x-dependent values it reads.
+//
+// Hash-consing merges what neighbouring shapes have in common (an edge shared by two triangles,
+// `x * 1/w`, ...).  For a region that a y value can switch off for a whole row this is the wrong
+// trade: shared values have to be computed ahead of the SKIP op, unconditionally, for every region
+// of the image, and they stay live across regions.  Re-deriving them inside the region from X, y
+// values and constants costs a few ops in the regions a row does enter and nothing in those it
+// skips.  Same ops on the same operands, so every value is unchanged bit for bit.
+struct Privatizer {
+    Dag &g;
+    std::vector<int32_t> &rowub;
+    std::vector<uint8_t> is_root, seen;
+    std::vector<int32_t> remap;                      // original node -> node after privatisation (-2: not yet)
+    std::unordered_map<int32_t, int32_t> memo;       // clones of the region being copied
+    uint32_t inst = 0;
+    size_t budget;
+
+    Privatizer(Dag &g_, std::vector<int32_t> &ub) : g(g_), rowub(ub), is_root(g_.n.size(), 0), seen(g_.n.size(), 0),
+                                                     remap(g_.n.size(), -2), budget(3 * g_.n.size() + 1024) {}
+
+    bool x_op(int32_t i) const { return i >= 0 && g.n[i].op < D_CONST && (g.n[i].dep & DEP_X); }
+
+    size_t x_cone(int32_t root, size_t cap) const {  // x-dependent ops below root (root included), counted up to cap
+        std::unordered_set<int32_t> in;
+        std::vector<int32_t> st{root};
+        while (!st.empty() && in.size() <= cap) {
+            const int32_t v = st.back(); st.pop_back();
+            if (!x_op(v) || !in.insert(v).second) continue;
+            st.push_back(g.n[v].a); st.push_back(g.n[v].b);
+        }
+        return in.size();
+    }
+    void select(int32_t i) {                         // outermost bounded conjunctions, seen from the channel roots
+        if (!x_op(i) || seen[i]) return;
+        seen[i] = 1;
+        if (rowub[i] >= 0) {
+            const size_t sz = x_cone(i, MAX_REGION / 2);
+            if (sz >= MIN_ROW_REGION && sz <= MAX_REGION / 2 && sz <= budget) { is_root[i] = 1; budget -= sz; return; }
+        }
+        select(g.n[i].a); select(g.n[i].b);
+    }
+    int32_t clone(int32_t i) {
+        if (!x_op(i)) return i;                      // leaves, constants and y-only values stay shared
+        auto it = memo.find(i);
+        if (it != memo.end()) return it->second;
+        DNode d = g.n[i];
+        if (d.a >= 0) d.a = clone(d.a);
+        if (d.b >= 0) d.b = clone(d.b);
+        d.inst = inst;
+        const int32_t r = g.intern(d);
+        memo.emplace(i, r);
+        return r;
+    }
+    int32_t map(int32_t i) {
+        if (i < 0 || (size_t)i >= remap.size()) return i;
+        if (remap[i] != -2) return remap[i];
+        int32_t r = i;
+        if (is_root[i]) {
+            inst++; memo.clear();
+            r = clone(i);
+            rowub.resize(g.n.size(), -1);
+            rowub[r] = rowub[i];
+        } else if (x_op(i)) {
+            DNode d = g.n[i];
+            const int32_t a = map(d.a), b = map(d.b);
+            if (a != d.a || b != d.b) { d.a = a; d.b = b; r = g.intern(d); }
+        }
+        remap[i] = r;
+        return r;
+    }
+};
+
 // One scheduled tape op.
 struct SItem {
     int32_t node;          // NODE: the computing node; OUT: the node read; SKIP: the guard
@@ -405,9 +482,6 @@ struct Section {
 };
 
 constexpr size_t MIN_REGION = 6;                // smallest exclusive cone worth a SKIP op
-constexpr size_t MIN_ROW_REGION = 12;           // ... worth a row-level SKIP op (guard = a y value)
-constexpr size_t MAX_REGION = 0x1FFF;           // aux field
-
 struct Lowerer {
     const Dag &g;
     std::vector<uint8_t> sin_bounded;           // per node: Sin/StepSin argument proven inside reduce_sincos range
@@ -752,26 +826,27 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         rowub.resize(g.n.size(), -1);
     }
 
-    const size_t N = g.n.size();
-    // reachability from the roots
-    std::vector<uint8_t> reach(N, 0);
-    {
+    auto mark_reach = [&]() {                   // reachability from the channel roots
+        std::vector<uint8_t> r(g.n.size(), 0);
         std::vector<int32_t> st(roots, roots + 3);
         while (!st.empty()) {
             int32_t i = st.back(); st.pop_back();
-            if (reach[i]) continue;
-            reach[i] = 1;
+            if (r[i]) continue;
+            r[i] = 1;
             if (g.n[i].a >= 0) st.push_back(g.n[i].a);
             if (g.n[i].b >= 0) st.push_back(g.n[i].b);
         }
-    }
+        return r;
+    };
     auto is_op = [&](int32_t i) { return g.n[i].op < D_CONST; };
 
+    // census of the scene's own DAG (before row regions get private copies of shared values)
     maray_tape_info &info = t.info;
     memset(&info, 0, sizeof info);
     info.folded_ops = folded_scene;
     uint32_t max_app = 0;
-    for (size_t i = 0; i < N; i++) {
+    std::vector<uint8_t> reach = mark_reach();
+    for (size_t i = 0; i < g.n.size(); i++) {
         if (!reach[i]) continue;
         info.dag_nodes++;
         if (!is_op((int32_t)i)) continue;
@@ -786,6 +861,16 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         if (g.n[i].op == MARAY_OP_APP || g.n[i].op == MARAY_OP_TEXDIM) max_app = std::max(max_app, g.n[i].aux + 1);
     }
     info.n_app = max_app;
+
+    if (!rowub.empty() && opts.no_private_regions == 0) {
+        Privatizer pv(g, rowub);
+        for (int c = 0; c < 3; c++) pv.select(roots[c]);
+        for (int c = 0; c < 3; c++) roots[c] = pv.map(roots[c]);
+        rowub.resize(g.n.size(), -1);
+        info.private_regions = pv.inst;
+        reach = mark_reach();
+    }
+    const size_t N = g.n.size();
 
     Lowerer L(g);
     L.regions = opts.no_skips == 0;

@@ -232,3 +232,21 @@ def test_gen_to_image_and_png_roundtrip(tmp_path, chess_bytes):
     from PIL import Image
     assert np.array_equal(np.asarray(Image.open(p).convert('RGB')), img)
     assert np.array_equal(M.png_read(p), img)
+
+
+def test_jit_in_a_process_that_imported_torch_first(chess_bytes):
+    """bench.py imports PyTorch before the library, and PyTorch brings its own (older) hiprtc / comgr, which then
+    compiles the specialised kernels instead of /opt/rocm's.  Same raster either way."""
+    import subprocess
+    import sys
+    g = json.load(open(os.path.join(GOLDEN, 'chess_1024.json')))
+    code = ('import torch, hashlib, sys; sys.path.insert(0, %r); import maray_amd as M\n'
+            'assert torch.cuda.is_available()\n'
+            's = M.Scene(open(%r, "rb").read()); t = s.lower(); c = M.Context(t, backend=M.BACKEND_JIT)\n'
+            'g8, _ = c.render_rows(1024, 1024, 0, 1024, want_f64=False)\n'
+            'print(c.kernel_name, hashlib.sha256(g8.tobytes()).hexdigest())\n'
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(GOLDEN, 'chess.maray')))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    name, digest = out.stdout.split()[-2:]
+    assert name == 'maray_jit_pixels' and digest == g['rgb8_sha256']

@@ -84,9 +84,14 @@ def test_chess_tape_census(chess_bytes):
     assert unfused['op_histogram'][tape_eval.OP['SIN']] == 256 and unfused['alg_ops'] == plain['alg_ops']
     assert plain['sin_ops'] == plain['sin_bounded'] == 256      # interval analysis: |arg| < 105414350 everywhere
     # default lowering: same computing ops + SKIP ops; row bounds add y values and ROW work
+    shared = M.Scene(chess_bytes).lower(private_regions=False).info
+    assert shared['folded_ops'] == 535 and shared['alg_ops'] == plain['alg_ops'] and shared['private_regions'] == 0
+    assert shared['n_pix_ops'] == plain['n_pix_ops'] + shared['skip_ops']
+    # ... and every row region re-derives the shared x-dependent values it reads (a few hundred more ops in the
+    # tape, executed only on the rows that enter the region); the census of the scene itself is unchanged
     info = M.Scene(chess_bytes).lower().info
-    assert info['folded_ops'] == 535 and info['alg_ops'] == plain['alg_ops']
-    assert info['n_pix_ops'] == plain['n_pix_ops'] + info['skip_ops']
+    assert info['folded_ops'] == 535 and info['alg_ops'] == plain['alg_ops'] and info['private_regions'] == 128
+    assert shared['n_pix_ops'] < info['n_pix_ops'] < shared['n_pix_ops'] + 600
     assert info['skip_ops'] > 800 and info['n_yvals'] > plain['n_yvals'] and info['n_row_ops'] > plain['n_row_ops']
     assert info['n_pix_slots'] <= 96          # hoisting shared nodes out of skip regions costs some
     nocommute = M.Scene(chess_bytes).lower(plain_cse=True, skips=False).info
