@@ -90,7 +90,9 @@ typedef struct maray_lower_opts {
     uint32_t no_row_guards; /* 1 = no row-level SKIPZ ops (guards that are y values: bounds of a boolean over a whole row) */
     uint32_t no_private_regions; /* 1 = row regions share hash-consed values with the rest of the tape (computed ahead of the
                               SKIP op, unconditionally); 0 = each row region re-derives the x-dependent values it reads (default) */
-    uint32_t reserved[2];
+    uint32_t no_rebalance; /* 1 = keep chains of one boolean connective (max(t1, max(t2, ...))) as written; 0 = rebuild them as
+                              balanced trees, whose sub-trees get row-level SKIP ops of their own (default) */
+    uint32_t reserved[1];
 } maray_lower_opts;
 
 typedef struct maray_tape_info {
@@ -105,6 +107,7 @@ typedef struct maray_tape_info {
     uint32_t bool_ops;         /* PIXEL ops whose value is provably +0.0 or 1.0 */
     uint32_t sin_ops, sin_bounded;   /* Sin/StepSin ops, and how many have a proven-bounded argument */
     uint32_t private_regions;  /* row regions that got private copies of the shared x-dependent values they read */
+    uint32_t rebalanced_chains; /* boolean OR / AND chains rebuilt as balanced trees */
     uint32_t op_histogram[MARAY_OP_COUNT];   /* PIXEL section */
 } maray_tape_info;
 

@@ -31,7 +31,7 @@ class TapeInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in
                 ('n_consts', 'n_row_ops', 'n_row_slots', 'n_yvals', 'n_pix_ops', 'n_pix_slots', 'n_app', 'alg_ops',
                  'alg_ops_xy', 'alg_ops_x', 'alg_ops_y', 'alg_ops_uniform', 'folded_ops', 'dag_nodes',
-                 'acc_operands', 'skip_ops', 'bool_ops', 'sin_ops', 'sin_bounded', 'private_regions')] + [('op_histogram', C.c_uint32 * OP_COUNT)]
+                 'acc_operands', 'skip_ops', 'bool_ops', 'sin_ops', 'sin_bounded', 'private_regions', 'rebalanced_chains')] + [('op_histogram', C.c_uint32 * OP_COUNT)]
 
 
 class Texture(C.Structure):
@@ -40,7 +40,7 @@ class Texture(C.Structure):
 
 class LowerOpts(C.Structure):
     _fields_ = [('hoist_rows', C.c_uint32), ('plain_cse', C.c_uint32), ('no_fuse', C.c_uint32), ('no_skips', C.c_uint32), ('no_row_guards', C.c_uint32),
-                ('no_private_regions', C.c_uint32), ('reserved', C.c_uint32 * 2)]
+                ('no_private_regions', C.c_uint32), ('no_rebalance', C.c_uint32), ('reserved', C.c_uint32 * 1)]
 
 
 class CtxOpts(C.Structure):
@@ -201,14 +201,14 @@ class Scene:
     def rescale(self, sx, sy):
         _check(lib().maray_scene_rescale(self._h, sx, sy))
 
-    def lower(self, hoist_rows=True, plain_cse=False, fuse=True, skips=True, row_guards=True, private_regions=True):
-        return Tape(self, hoist_rows, plain_cse, fuse, skips, row_guards, private_regions)
+    def lower(self, hoist_rows=True, plain_cse=False, fuse=True, skips=True, row_guards=True, private_regions=True, rebalance=True):
+        return Tape(self, hoist_rows, plain_cse, fuse, skips, row_guards, private_regions, rebalance)
 
 
 class Tape:
     """Lowered program (include/maray_tape.h)."""
 
-    def __init__(self, scene, hoist_rows=True, plain_cse=False, fuse=True, skips=True, row_guards=True, private_regions=True):
+    def __init__(self, scene, hoist_rows=True, plain_cse=False, fuse=True, skips=True, row_guards=True, private_regions=True, rebalance=True):
         o = LowerOpts()
         o.hoist_rows = 1 if hoist_rows else 0
         o.plain_cse = 1 if plain_cse else 0
@@ -216,6 +216,7 @@ class Tape:
         o.no_skips = 0 if skips else 1
         o.no_row_guards = 0 if row_guards else 1
         o.no_private_regions = 0 if private_regions else 1
+        o.no_rebalance = 0 if rebalance else 1
         h = C.c_void_p()
         _check(lib().maray_lower(scene._h, C.byref(o), C.byref(h)))
         self._h = h

@@ -69,6 +69,14 @@ bool jit_row_guards_enabled()
     return !(e_ && e_[0] == '0');
 }
 
+// f64 values a VALU instruction encodes as an inline constant (gfx9: 0, +-0.5, +-1, +-2, +-4, 1/(2 pi))
+bool inline_f64(uint64_t bits)
+{
+    const uint64_t mag = bits & 0x7fffffffffffffffull;
+    return mag == 0 || mag == 0x3fe0000000000000ull || mag == 0x3ff0000000000000ull || mag == 0x4000000000000000ull ||
+           mag == 0x4010000000000000ull || bits == 0x3fc45f306dc9c882ull;
+}
+
 std::string lit(double v)
 {
     if (v != v) return "__builtin_nan(\"\")";
@@ -106,6 +114,13 @@ struct Emitter {
     uint32_t guard_first = 0, guard_words = 0;   // y values >= guard_first are SKIP guards packed as bits (32 per word)
     std::vector<uint8_t> is_bool_op;             // out: per op of the last section(), was its value carried as a bool
     std::vector<uint8_t> bool_hint;              // in: the same from a dry run without row guards (types their regions)
+    // Constants that no VALU instruction can encode inline are read from a table in constant memory, laid out in the
+    // order the code reads them (one entry per use, shared inside a basic block): the compiler then fetches a block's
+    // constants with a few s_load_dwordx4/x8/x16 instead of two s_mov_b32 per use, and the scalar unit -- which also
+    // does all the boolean algebra and every region's branch -- is what bounds this kernel.
+    bool ktab = false;
+    std::vector<double> ktab_vals;
+    std::unordered_map<uint64_t, uint32_t> ktab_block;
     explicit Emitter(const maray_program &p) : P(p) {}
 
     void section(const uint64_t *ops, uint32_t n, uint32_t n_slots, bool pixel, const char *prefix)
@@ -128,6 +143,11 @@ struct Emitter {
                 const double c = P.consts[idx];
                 t.d = lit(c);
                 uint64_t bits; memcpy(&bits, &c, 8);
+                if (ktab && !inline_f64(bits)) {
+                    auto it = ktab_block.find(bits);
+                    if (it == ktab_block.end()) { it = ktab_block.emplace(bits, (uint32_t)ktab_vals.size()).first; ktab_vals.push_back(c); }
+                    t.d = "mr_kc[" + std::to_string(it->second) + "]";
+                }
                 if (bits == 0x3ff0000000000000ull) { t.kind = BOOL; t.b = "MR_ALL"; }
                 else if (bits == 0) { t.kind = BOOL; t.b = "MR_NONE"; }
                 return &t;
@@ -191,6 +211,7 @@ struct Emitter {
                 const std::string &test = cond;
                 out += cold ? "    if (__builtin_expect(" + test + ", 0)) {\n" : "    if (" + test + ") {\n";
                 open.push_back(Open{end, typed_bool, nz});
+                ktab_block.clear();
                 continue;
             }
             if (op == MARAY_OP_OUT) {
@@ -250,6 +271,7 @@ struct Emitter {
             }
             const bool closes = !open.empty() && open.back().end == i;
             if (closes) {
+                ktab_block.clear();
                 // the AND / OR that ends a region: assign the variable declared before the `if`
                 const Open o = open.back();
                 open.pop_back();
@@ -359,7 +381,7 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
          "__device__ inline double mr_defer_sin(double) { mr_slow_tile = 1u; return 0.0; }\n"
          "#define MR_SIN_HUGE(x) mr_defer_sin(x)   // plain Sin ops: flag the tile from the (rare) branch\n"
          "#include \"device_math.h\"\n"
-         "typedef const __attribute__((address_space(4))) double *mr_kptr;\n\n";
+         "typedef const __attribute__((address_space(4))) double *mr_kptr;\n/*MR_KTAB*/\n";
     s += "extern \"C\" __global__ void __launch_bounds__(256" + (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string()) +
          ") maray_jit_pixels(unsigned char *__restrict__ rgb8, double *__restrict__ rgb64,\n"
          "                                                                    const double *__restrict__ yvals, const MarayTex *__restrict__ tex,\n"
@@ -377,7 +399,7 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
          "    const __attribute__((address_space(4))) unsigned *yw = (const __attribute__((address_space(4))) unsigned *)yv;\n"
          "    double o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"
          "    float mr_defer = 0.0f;                     // fused Step(Sin) ops count their undecided cases in here\n"
-         "    (void)X; (void)Y; (void)yv; (void)yw; (void)tex; (void)gwords;\n";
+         "    (void)X; (void)Y; (void)yv; (void)yw; (void)tex; (void)gwords;\n/*MR_KBASE*/";
     if (E.guard_words) {
         s += "    const __attribute__((address_space(4))) unsigned *gk = (const __attribute__((address_space(4))) unsigned *)(gwords + (size_t)r * " +
              std::to_string(E.guard_words) + "u);\n";
@@ -390,7 +412,25 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
         D.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
         E.bool_hint = D.is_bool_op;
     }
+    {
+        const char *e_ = getenv("MARAY_JIT_KTAB");
+        E.ktab = !(e_ && e_[0] == '0');
+    }
     E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+    {
+        std::string tab;
+        if (!E.ktab_vals.empty()) {
+            tab = "__constant__ double mr_kc_tab[" + std::to_string(E.ktab_vals.size()) + "] = {";
+            for (size_t j = 0; j < E.ktab_vals.size(); j++) { tab += (j % 6 ? " " : "\n    "); tab += lit(E.ktab_vals[j]); tab += ","; }
+            tab += "\n};\n";
+        }
+        s.replace(s.find("/*MR_KTAB*/"), 11, tab);
+        // the table's address, made opaque: left visible, the compiler re-derives it (s_getpc + s_add + s_addc) at every load
+        s.replace(s.find("/*MR_KBASE*/"), 12, E.ktab_vals.empty() ? "" :
+                  "    unsigned long long mr_kbase = (unsigned long long)mr_kc_tab;\n"
+                  "    asm volatile(\"\" : \"+s\"(mr_kbase));\n"
+                  "    const mr_kptr mr_kc = (mr_kptr)mr_kbase;\n");
+    }
     s += "    if (mr_defer != 0.0f && x < w) mr_slow_tile = 1u;\n";
     s += "    if (x < w) {\n"
          "        const size_t p = ((size_t)r * w + x) * 3;\n"

@@ -392,6 +392,72 @@ struct RowBounds {
 constexpr size_t MIN_ROW_REGION = 12;           // smallest region worth a row-level SKIP op (guard = a y value)
 constexpr size_t MAX_REGION = 0x1FFF;           // aux field
 
+
+// Long chains of one boolean connective -- max(t1, max(t2, max(t3, ...))), the way a scene paints
+// shape over shape -- are rebuilt as balanced trees over the same operands in the same order.
+// On {+0.0, 1.0} max is OR and mul / min are AND: associative and commutative bit for bit, so every
+// value is unchanged.  A balanced tree has sub-trees of 4, 16, ... shapes whose bound over a row is
+// still selective, which lets one row-level SKIP op drop a whole group of shapes (a right-deep
+// chain only has "this shape" and "all the remaining ones").
+struct Rebalancer {
+    Dag &g;
+    const std::vector<uint8_t> &isbool;
+    std::vector<uint32_t> users;
+    std::vector<int32_t> remap;
+    uint32_t rebuilt = 0;
+
+    Rebalancer(Dag &g_, const std::vector<uint8_t> &b, const int32_t roots[3]) : g(g_), isbool(b), users(g_.n.size(), 0), remap(g_.n.size(), -2) {
+        std::vector<uint8_t> seen(g.n.size(), 0);
+        std::vector<int32_t> st(roots, roots + 3);
+        for (int c = 0; c < 3; c++) users[roots[c]]++;
+        while (!st.empty()) {
+            const int32_t i = st.back(); st.pop_back();
+            if (seen[i]) continue;
+            seen[i] = 1;
+            for (int32_t c : {g.n[i].a, g.n[i].b}) if (c >= 0) { users[c]++; st.push_back(c); }
+        }
+    }
+    int cls(int32_t i) const {                       // 1: OR, 2: AND of two booleans, 0: anything else
+        if (i < 0 || (size_t)i >= isbool.size()) return 0;
+        const DNode &d = g.n[i];
+        if (!isbool[i] || d.a < 0 || d.b < 0 || !isbool[d.a] || !isbool[d.b]) return 0;
+        if (d.op == MARAY_OP_MAX) return 1;
+        if (d.op == MARAY_OP_MUL || d.op == MARAY_OP_MIN) return 2;
+        return 0;
+    }
+    void leaves(int32_t i, int c, bool top, std::vector<int32_t> &out) {
+        if (cls(i) == c && (top || users[i] == 1)) {
+            const DNode d = g.n[i];
+            leaves(d.a, c, false, out);
+            leaves(d.b, c, false, out);
+        } else out.push_back(map(i));
+    }
+    int32_t tree(const std::vector<int32_t> &l, size_t lo, size_t hi, uint8_t op) {
+        if (hi - lo == 1) return l[lo];
+        const size_t mid = lo + (hi - lo + 1) / 2;
+        return g.binary(op, tree(l, lo, mid, op), tree(l, mid, hi, op));
+    }
+    int32_t map(int32_t i) {
+        if (i < 0 || (size_t)i >= remap.size()) return i;
+        if (remap[i] != -2) return remap[i];
+        int32_t r = i;
+        const int c = cls(i);
+        const DNode d = g.n[i];
+        bool done = false;
+        if (c) {
+            std::vector<int32_t> l;
+            leaves(i, c, true, l);
+            if (l.size() >= 4) { r = tree(l, 0, l.size(), c == 1 ? MARAY_OP_MAX : MARAY_OP_MIN); rebuilt++; done = true; }
+        }
+        if (!done && d.op < D_CONST) {
+            const int32_t a = map(d.a), b = map(d.b);
+            if (a != d.a || b != d.b) { DNode e = d; e.a = a; e.b = b; r = g.intern(e); }
+        }
+        remap[i] = r;
+        return r;
+    }
+};
+
 // Gives every row region its own copy of the x-dependent values it reads.
 //
 // Hash-consing merges what neighbouring shapes have in common (an edge shared by two triangles,
@@ -427,7 +493,7 @@ struct Privatizer {
     void select(int32_t i) {                         // outermost bounded conjunctions, seen from the channel roots
         if (!x_op(i) || seen[i]) return;
         seen[i] = 1;
-        if (rowub[i] >= 0) {
+        if (rowub[i] >= 0 && g.n[i].op != MARAY_OP_MAX) {    // a shape (conjunction); groups of shapes (OR) stay shared structure
             const size_t sz = x_cone(i, MAX_REGION / 2);
             if (sz >= MIN_ROW_REGION && sz <= MAX_REGION / 2 && sz <= budget) { is_root[i] = 1; budget -= sz; return; }
         }
@@ -457,7 +523,11 @@ struct Privatizer {
         } else if (x_op(i)) {
             DNode d = g.n[i];
             const int32_t a = map(d.a), b = map(d.b);
-            if (a != d.a || b != d.b) { d.a = a; d.b = b; r = g.intern(d); }
+            if (a != d.a || b != d.b) {
+                d.a = a; d.b = b; r = g.intern(d);
+                rowub.resize(g.n.size(), -1);
+                rowub[r] = rowub[i];                 // a group of shapes keeps its bound
+            }
         }
         remap[i] = r;
         return r;
@@ -497,6 +567,7 @@ struct Lowerer {
     std::vector<double> consts;
     std::vector<int32_t> yval_of;               // node -> y value index or -1
     int row_depth = 0;
+    int32_t row_reentry = -1;
 
     explicit Lowerer(const Dag &g_) : g(g_), yval_of(g_.n.size(), -1) {}
 
@@ -594,7 +665,10 @@ struct Lowerer {
     void visit(int32_t i, Section &sec) {
         if (i < 0 || visited[i] || !in_section[i]) return;
         // Row-level short circuit: a y value proves this boolean 0 on the whole row -> skip all that only feeds it.
-        if (regions && !rowub.empty() && rowub[i] >= 0 && row_depth == 0) {      // outermost only: inner ones would mostly be true
+        // not inside a conjunction's row region: bounds of its factors would mostly be true there
+        const bool reentry = i == row_reentry;       // the call below that schedules the region's own contents
+        row_reentry = -1;
+        if (regions && !reentry && !rowub.empty() && rowub[i] >= 0 && row_depth == 0) {
             const std::vector<int32_t> r = reach(i);
             const std::unordered_set<int32_t> cone = self_cone(i, r);
             if (cone.size() >= MIN_ROW_REGION && cone.size() <= MAX_REGION / 2) {
@@ -602,9 +676,11 @@ struct Lowerer {
                 const size_t mark = sec.sched.size();
                 SItem sk; sk.node = rowub[i]; sk.target = i; sk.nz = 0;
                 sec.sched.push_back(sk);
-                row_depth++;
+                const int conj = g.n[i].op != MARAY_OP_MAX;
+                row_depth += conj;
+                row_reentry = i;
                 visit(i, sec);                                               // the usual schedule, wave-level regions included
-                row_depth--;
+                row_depth -= conj;
                 if (sec.sched.size() - mark - 1 > MAX_REGION) sec.sched.erase(sec.sched.begin() + (long)mark);
                 else used_rowguards.push_back(rowub[i]);
                 return;
@@ -807,19 +883,33 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         }
         return isb;
     };
+    const bool row_guards = opts.no_skips == 0 && opts.hoist_rows != 0 && opts.no_row_guards == 0;
+    uint32_t rebalanced = 0;
+    if (row_guards && opts.no_rebalance == 0) {
+        const std::vector<uint8_t> isb = bool_typing();
+        Rebalancer rb(g, isb, roots);
+        for (int c = 0; c < 3; c++) roots[c] = rb.map(roots[c]);
+        rebalanced = rb.rebuilt;
+    }
     const size_t N0 = g.n.size();
     const uint32_t folded_scene = g.folded;     // constant ops folded in the scene itself (the row bounds fold more)
     std::vector<int32_t> rowub;
-    if (opts.no_skips == 0 && opts.hoist_rows != 0 && opts.no_row_guards == 0) {
+    if (row_guards) {
         const std::vector<uint8_t> isb0 = bool_typing();
         const std::vector<Ival> iv0 = intervals(g);
         const std::vector<Mono> mono0 = monotonicity(g, iv0);
         RowBounds rb(g, isb0, mono0);
         rowub.assign(N0, -1);
+        std::vector<uint32_t> shapes(N0, 1);          // operands of the OR tree below a node
         for (size_t i = 0; i < N0; i++) {
             const uint8_t op = g.n[i].op;
-            // conjunctions only: an OR accumulating many shapes has a bound that is almost always true
-            if (!isb0[i] || !(g.n[i].dep & DEP_X) || !(op == MARAY_OP_MUL || op == MARAY_OP_MIN)) continue;
+            if (!isb0[i] || !(g.n[i].dep & DEP_X)) continue;
+            if (op == MARAY_OP_MAX && isb0[g.n[i].a] && isb0[g.n[i].b]) shapes[i] = shapes[g.n[i].a] + shapes[g.n[i].b];
+            // conjunctions, and ORs over a few shapes (two levels of a balanced tree: groups of 3-4 and of 9-16);
+            // an OR accumulating many shapes has a bound that is almost always true
+            const bool conj = op == MARAY_OP_MUL || op == MARAY_OP_MIN;
+            const bool group = op == MARAY_OP_MAX && ((shapes[i] >= 3 && shapes[i] <= 4) || (shapes[i] >= 9 && shapes[i] <= 16));
+            if (!conj && !group) continue;
             const int32_t ub = rb.bounds((int32_t)i).first;
             if (g.n[ub].op < D_CONST) rowub[i] = ub;          // a real y-only op (not folded to a constant)
         }
@@ -861,6 +951,7 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         if (g.n[i].op == MARAY_OP_APP || g.n[i].op == MARAY_OP_TEXDIM) max_app = std::max(max_app, g.n[i].aux + 1);
     }
     info.n_app = max_app;
+    info.rebalanced_chains = rebalanced;
 
     if (!rowub.empty() && opts.no_private_regions == 0) {
         Privatizer pv(g, rowub);
