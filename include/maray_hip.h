@@ -162,6 +162,9 @@ int maray_hip_time_rows(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uint3
 /* MARAY_BACKEND_JIT, offline: the HIP source generated for a tape (free with
  * maray_free) and the gfx950 code object hiprtc builds from it (needs no GPU). */
 int maray_jit_source(const maray_program *prog, char **src_out);
+/* ... and of the ROW kernel (one work-item per row; *n_chunks = how many independent chunks the
+ * ROW section was cut into, evaluated side by side as blockIdx.y; may be NULL). */
+int maray_jit_source_rows(const maray_program *prog, char **src_out, uint32_t *n_chunks);
 int maray_jit_build(const maray_program *prog, void **code_out, size_t *len_out);
 /* Name of the dominant kernel (for matching rocprofv3 rows). */
 const char *maray_hip_kernel_name(const maray_ctx *c);

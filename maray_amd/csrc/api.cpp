@@ -376,12 +376,24 @@ int maray_jit_source(const maray_program *prog, char **src_out)
     });
 }
 
+int maray_jit_source_rows(const maray_program *prog, char **src_out, uint32_t *n_chunks)
+{
+    return guard([&] {
+        REQUIRE(prog && src_out, "null argument");
+        const std::string s = jit_source_rows(*prog, n_chunks);
+        *src_out = (char *)malloc(s.size() + 1);
+        if (!*src_out) throw Error{MARAY_E_INTERNAL, "out of memory"};
+        memcpy(*src_out, s.c_str(), s.size() + 1);
+    });
+}
+
 int maray_jit_build(const maray_program *prog, void **code_out, size_t *len_out)
 {
     return guard([&] {
         REQUIRE(prog && code_out && len_out, "null argument");
         std::vector<char> code;
         std::string log;
+        if (prog->n_row_ops) jit_compile(jit_source_rows(*prog), code, log);      // must build too; its code object is not returned
         jit_compile(jit_source(*prog), code, log);
         *code_out = malloc(code.size() ? code.size() : 1);
         if (!*code_out) throw Error{MARAY_E_INTERNAL, "out of memory"};

@@ -32,7 +32,7 @@ int hip_device_count();
 Backend *make_tape_backend(int device, const maray_program &prog, const maray_texture *tex, uint32_t n_tex, bool lds_variant);
 Backend *make_jit_backend(int device, const maray_program &prog, const maray_texture *tex, uint32_t n_tex);
 std::string jit_source(const maray_program &prog, int min_waves = 8);   // PIXEL kernel source (__launch_bounds__(256, min_waves)); throws Error
-std::string jit_source_rows(const maray_program &prog);   // ROW kernel source
+std::string jit_source_rows(const maray_program &prog, uint32_t *n_chunks_out = nullptr);   // ROW kernel source (blockIdx.y = chunk)
 void jit_compile(const std::string &src, std::vector<char> &code, std::string &log);     // hiprtc, gfx950; throws Error
 void validate_program(const maray_program &p);
 

@@ -24,6 +24,12 @@ MARAY_DEV double mr_mask_f64(mr_mask m, unsigned on, unsigned off)
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(off), "v"(on), "s"(m));
     return __builtin_bit_cast(double, (unsigned long long)hi << 32);
 }
+// a value every lane holds alike (read from LDS) -> SGPR pair
+MARAY_DEV mr_mask mr_uniform64(mr_mask v)
+{
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((mr_mask)hi << 32) | lo;
+}
 #define mr_pos(m) mr_mask_f64(m, 0x3ff00000u, 0u)              /* +1.0 : +0.0 */
 #define mr_neg01(m) mr_mask_f64(m, 0xbff00000u, 0x80000000u)   /* -1.0 : -0.0 */
 

@@ -110,8 +110,7 @@ struct Emitter {
     std::vector<Val> vals;   // one per op of the current section
     std::string yv_name = "yv";
     bool ignore_row_guards = false;
-    uint32_t row_out_limit = 0xFFFFFFFFu;        // ROW kernel: y values >= this are not produced
-    uint32_t guard_first = 0, guard_words = 0;   // y values >= guard_first are SKIP guards packed as bits (32 per word)
+    uint32_t guard_first = 0, guard_words = 0;   // y values >= guard_first are SKIP guards; the kernel packs them as bits, 64 per word
     std::vector<uint8_t> is_bool_op;             // out: per op of the last section(), was its value carried as a bool
     std::vector<uint8_t> bool_hint;              // in: the same from a dry run without row guards (types their regions)
     // Constants that no VALU instruction can encode inline are read from a table in constant memory, laid out in the
@@ -192,7 +191,7 @@ struct Emitter {
                 if (row_guard && !nz && guard_words && MARAY_REF_INDEX(gref) >= guard_first) {
                     // a row bound: one bit of a guard word that sits in an SGPR since the kernel's prologue
                     const uint32_t k = MARAY_REF_INDEX(gref) - guard_first;
-                    cond = "(gw" + std::to_string(k / 32) + " & " + std::to_string(1u << (k % 32)) + "u) != 0u";
+                    cond = "(gq" + std::to_string(k / 64) + " & (1ull << " + std::to_string(k % 64) + ")) != 0ull";
                 } else if (row_guard) {
                     // a y value is uniform over the block: test its bits on the scalar unit, no ballot, no VALU
                     const std::string k = std::to_string(MARAY_REF_INDEX(gref));
@@ -215,7 +214,6 @@ struct Emitter {
                 continue;
             }
             if (op == MARAY_OP_OUT) {
-                if (!pixel && aux >= row_out_limit) continue;    // a guard the pixel kernel ignores: its cone is dead code
                 const std::string a = dbl(va, "m", i, 0);
                 out += pixel ? "    o" + std::to_string(aux) + " = " + a + ";\n"
                              : "    yout[" + std::to_string(aux) + "] = " + a + ";\n";
@@ -310,39 +308,91 @@ struct Emitter {
 
 }   // namespace
 
-// Source of the ROW kernel (one work-item per row).  Plain device_math.h: the
-// rare huge-argument tail of sin is a real (out-of-line) call here.
-std::string jit_source_rows(const maray_program &P)
+// The ROW section split into chunks that different wavefronts evaluate side by side.  One
+// work-item per row is all the parallelism a straight-line ROW kernel has (4096 rows = 64 waves,
+// each walking thousands of dependent f64 ops: ~45 us for chess, an eighth of the frame).  The y
+// values are independent outputs, so the tape is cut by outputs: chunk k keeps the ops its outputs
+// depend on (ops two chunks share are computed in both) and the rest become NOPs.  SKIP ops are
+// dropped -- legal for any evaluator, and 64 different rows rarely agree anyway.
+std::vector<std::vector<uint64_t>> split_row_tape(const maray_program &P, uint32_t out_limit)
+{
+    const uint32_t n = P.n_row_ops;
+    std::vector<std::array<int32_t, 2>> deps(n, {-1, -1});
+    std::vector<int32_t> slot_writer(P.n_row_slots ? P.n_row_slots : 1, -1);
+    std::vector<uint32_t> outs;
+    int32_t acc = -1;
+    auto producer = [&](uint32_t ref) -> int32_t {
+        const uint32_t kind = MARAY_REF_KIND(ref), idx = MARAY_REF_INDEX(ref);
+        if (kind == MARAY_K_SLOT) return slot_writer[idx];
+        if (kind == MARAY_K_SPEC && idx == MARAY_SPEC_ACC) return acc;
+        return -1;
+    };
+    for (uint32_t j = 0; j < n; j++) {
+        const uint64_t ins = P.row_ops[j];
+        const uint32_t op = MARAY_INS_OP(ins);
+        if (op == MARAY_OP_NOP || op == MARAY_OP_SKIPZ || op == MARAY_OP_SKIPNZ) continue;
+        if (op != MARAY_OP_TEXDIM) deps[j][0] = producer(MARAY_INS_A(ins));
+        if (op == MARAY_OP_OUT) { if (MARAY_INS_AUX(ins) < out_limit) outs.push_back(j); continue; }
+        if (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) deps[j][1] = producer(MARAY_INS_B(ins));
+        acc = (int32_t)j;
+        if (MARAY_INS_DST(ins) != MARAY_DST_NONE) slot_writer[MARAY_INS_DST(ins)] = (int32_t)j;
+    }
+    const uint32_t n_chunks = std::min<uint32_t>(16, std::max<uint32_t>(1, n / 640));
+    std::vector<std::vector<uint64_t>> chunks;
+    std::vector<uint32_t> stamp(n, 0);
+    std::vector<int32_t> st;
+    size_t next = 0;
+    for (uint32_t k = 1; next < outs.size(); k++) {
+        std::vector<uint64_t> tape(n, 0);           // 0 = NOP
+        const size_t budget = (n + n_chunks - 1) / n_chunks;
+        size_t cost = 0;
+        while (next < outs.size() && (cost < budget || chunks.size() + 1 == n_chunks)) {
+            st.push_back((int32_t)outs[next++]);
+            while (!st.empty()) {
+                const int32_t v = st.back(); st.pop_back();
+                if (v < 0 || stamp[v] == k) continue;
+                stamp[v] = k;
+                tape[v] = P.row_ops[v];
+                cost++;
+                st.push_back(deps[v][0]); st.push_back(deps[v][1]);
+            }
+        }
+        chunks.push_back(std::move(tape));
+    }
+    if (chunks.empty()) chunks.emplace_back(n, 0);
+    return chunks;
+}
+
+// Source of the ROW kernel: one work-item per row, one wavefront per block, blockIdx.y = chunk of
+// the ROW section.  Plain device_math.h: the rare huge-argument tail of sin is a real (out-of-line)
+// call here.
+std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out)
 {
     validate_program(P);
     Emitter E(P);
     // the interpreter (which drains deferred tiles from the same y-value table) does read the guard values
-    if (!jit_row_guards_enabled() && !may_defer_tiles(P)) E.row_out_limit = numeric_yvals(P);
+    uint32_t out_limit = 0xFFFFFFFFu;
+    if (!jit_row_guards_enabled() && !may_defer_tiles(P)) out_limit = numeric_yvals(P);
+    const std::vector<std::vector<uint64_t>> chunks = split_row_tape(P, out_limit);
+    if (n_chunks_out) *n_chunks_out = (uint32_t)chunks.size();
     std::string &s = E.out;
-    s += "// generated by libmaray_hip (jit_backend.cpp): ROW section, " + std::to_string(P.n_row_ops) + " ops\n";
+    s += "// generated by libmaray_hip (jit_backend.cpp): ROW section, " + std::to_string(P.n_row_ops) + " ops in " +
+         std::to_string(chunks.size()) + " chunks\n";
     s += "#include \"device_math.h\"\n\n";
-    s += "extern \"C\" __global__ void __launch_bounds__(256) maray_jit_rows(double *__restrict__ yvals, const MarayTex *__restrict__ tex,\n"
-         "                                                                  unsigned y0, unsigned rows, unsigned n_yvals, unsigned w)\n{\n"
-         "    const unsigned r = blockIdx.x * 256u + threadIdx.x;\n"
+    s += "extern \"C\" __global__ void __launch_bounds__(64) maray_jit_rows(double *__restrict__ yvals, const MarayTex *__restrict__ tex,\n"
+         "                                                                 unsigned y0, unsigned rows, unsigned n_yvals, unsigned w)\n{\n"
+         "    const unsigned r = blockIdx.x * 64u + threadIdx.x;\n"
          "    if (r >= rows) return;\n"
          "    const double Y = (double)(y0 + r), XMAX = (double)(w - 1u);\n"
          "    double *yout = yvals + (size_t)r * n_yvals;\n"
-         "    (void)Y; (void)XMAX; (void)tex; (void)yout;\n";
-    E.section(P.row_ops, P.n_row_ops, P.n_row_slots, false, "r");
-    s += "}\n\n";
-    // y values [first, first + n_guards) only gate SKIP ops: pack them (value != 0) 32 per word for the pixel kernel
-    s += "extern \"C\" __global__ void __launch_bounds__(256) maray_jit_pack(const double *__restrict__ yvals, unsigned *__restrict__ gwords,\n"
-         "                                                                  unsigned rows, unsigned n_yvals, unsigned first, unsigned n_guards, unsigned n_words)\n{\n"
-         "    const unsigned t = blockIdx.x * 256u + threadIdx.x;\n"
-         "    if (t >= rows * n_words) return;\n"
-         "    const unsigned r = t / n_words, j = t % n_words;\n"
-         "    unsigned wv = 0u;\n"
-         "    for (unsigned b = 0; b < 32u; b++) {\n"
-         "        const unsigned k = 32u * j + b;\n"
-         "        if (k < n_guards && yvals[(size_t)r * n_yvals + first + k] != 0.0) wv |= 1u << b;\n"
-         "    }\n"
-         "    gwords[t] = wv;\n"
-         "}\n";
+         "    (void)Y; (void)XMAX; (void)tex; (void)yout;\n"
+         "    switch (blockIdx.y) {\n";
+    for (size_t k = 0; k < chunks.size(); k++) {
+        s += "    case " + std::to_string(k) + ": {\n";
+        E.section(chunks[k].data(), P.n_row_ops, P.n_row_slots, false, "r");
+        s += "    } break;\n";
+    }
+    s += "    }\n}\n\n";
     return s;
 }
 
@@ -368,43 +418,72 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
     const uint32_t n_ynum = numeric_yvals(P);   // y values read as operands (a prefix of the table); the rest only gate SKIPs
     const bool y_lds = n_ynum > 0 && n_ynum <= 4096 && !(env_ylds && env_ylds[0] == '0');
     const uint32_t n_guards = P.n_yvals - n_ynum;
-    const uint32_t n_gwords = (n_guards + 31) / 32;
-    // Row-level SKIP ops (guard = a y value) are ignored by default here: measured on chess @4096^2 they halve the
-    // executed ops but hoist ~480 shared values to the top of the kernel, and the register pressure costs more than
-    // the skipped work saves (1.19 ms vs 1.01 ms).  The interpreter kernel takes them (2.8x).  MARAY_JIT_ROW_GUARDS=1
-    // turns them on: the guards then travel as bits, 32 per word, held in SGPRs from the kernel's prologue.
+    const uint32_t n_gwords = (n_guards + 63) / 64;
+    // Row-level SKIP ops (guard = a y value that bounds a boolean over the whole row): the block's prologue turns the
+    // row's guard values into bits (one coalesced load + ballot per 256 guards), 64 per word, and every wave keeps the
+    // words in SGPRs; a region's test is then one s_bitcmp1_b64.  MARAY_JIT_ROW_GUARDS=0 compiles them away.
     E.ignore_row_guards = !jit_row_guards_enabled();
-    if (!E.ignore_row_guards && n_gwords > 0 && n_gwords <= 24) { E.guard_first = n_ynum; E.guard_words = n_gwords; }
+    if (!E.ignore_row_guards && n_gwords > 0 && n_gwords <= 12) { E.guard_first = n_ynum; E.guard_words = n_gwords; }
     if (y_lds) E.yv_name = "mr_ylds";
     if (y_lds) s += "__shared__ double mr_ylds[" + std::to_string(n_ynum) + "];\n";
+    if (E.guard_words) s += "__shared__ unsigned long long mr_gq[" + std::to_string(E.guard_words) + "];\n";
+    const bool defer = may_defer_tiles(P);
     s += "__shared__ unsigned mr_slow_tile;\n"
          "__device__ inline double mr_defer_sin(double) { mr_slow_tile = 1u; return 0.0; }\n"
          "#define MR_SIN_HUGE(x) mr_defer_sin(x)   // plain Sin ops: flag the tile from the (rare) branch\n"
          "#include \"device_math.h\"\n"
          "typedef const __attribute__((address_space(4))) double *mr_kptr;\n/*MR_KTAB*/\n";
+    // A block owns `tiles` consecutive 256-pixel tiles of one row (blockIdx.y) and walks them in a loop, so the row's
+    // y values and guard bits are staged once per block, not once per tile.  (A program that may defer tiles is
+    // launched with tiles = 1: the work list names 256-pixel tiles.)
     s += "extern \"C\" __global__ void __launch_bounds__(256" + (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string()) +
          ") maray_jit_pixels(unsigned char *__restrict__ rgb8, double *__restrict__ rgb64,\n"
          "                                                                    const double *__restrict__ yvals, const MarayTex *__restrict__ tex,\n"
          "                                                                    unsigned *__restrict__ tile_list, unsigned tile_base,\n"
-         "                                                                    const unsigned *__restrict__ gwords,\n"
-         "                                                                    unsigned w, unsigned y0, unsigned n_yvals)\n{\n"
-         "    const unsigned x = blockIdx.x * 256u + threadIdx.x;\n"
+         "                                                                    unsigned w, unsigned y0, unsigned n_yvals, unsigned tiles)\n{\n"
          "    const unsigned r = blockIdx.y;\n"
-         "    if (threadIdx.x == 0) mr_slow_tile = 0u;\n";
-    if (y_lds)
-        s += "    for (unsigned i = threadIdx.x; i < " + std::to_string(n_ynum) + "u; i += 256u) mr_ylds[i] = yvals[(size_t)r * n_yvals + i];\n";
+         "    const double *yrow = yvals + (size_t)r * n_yvals;\n";
+    if (defer) s += "    if (threadIdx.x == 0) mr_slow_tile = 0u;\n";
+    // every load of the prologue is issued before the first use: one memory latency, not one per round
+    const uint32_t y_rounds = y_lds ? (n_ynum + 255) / 256 : 0, g_rounds = (E.guard_words * 64 + 255) / 256;
+    for (uint32_t k = 0; k < y_rounds; k++) {
+        const std::string i = std::to_string(k * 256) + "u + threadIdx.x";
+        s += "    const double ys" + std::to_string(k) + " = " + i + " < " + std::to_string(n_ynum) + "u ? yrow[" + i + "] : 0.0;\n";
+    }
+    for (uint32_t k = 0; k < g_rounds; k++) {       // guard values -> bits: lane i of round k owns guard 256 k + i
+        const std::string i = std::to_string(k * 256) + "u + threadIdx.x";
+        s += "    const double gs" + std::to_string(k) + " = " + i + " < " + std::to_string(n_guards) + "u ? yrow[" +
+             std::to_string(n_ynum) + "u + " + i + "] : 0.0;\n";
+    }
+    for (uint32_t k = 0; k < y_rounds; k++) {
+        const std::string i = std::to_string(k * 256) + "u + threadIdx.x";
+        s += "    if (" + i + " < " + std::to_string(n_ynum) + "u) mr_ylds[" + i + "] = ys" + std::to_string(k) + ";\n";
+    }
+    for (uint32_t k = 0; k < g_rounds; k++) {
+        const std::string i = "(" + std::to_string(k * 256) + "u + threadIdx.x)";
+        s += "    {\n        const mr_mask gm = mr_ballot(gs" + std::to_string(k) + " != 0.0);\n"
+             "        if ((threadIdx.x & 63u) == 0u && " + i + " < " + std::to_string(E.guard_words * 64) + "u) mr_gq[" + i + " >> 6] = gm;\n    }\n";
+    }
     s += "    __syncthreads();\n"
-         "    const double X = (double)x, Y = (double)(y0 + r);\n"
-         "    mr_kptr yv = (mr_kptr)(yvals + (size_t)r * n_yvals);\n"
+         "    const double Y = (double)(y0 + r);\n"
+         "    mr_kptr yv = (mr_kptr)yrow;\n"
          "    const __attribute__((address_space(4))) unsigned *yw = (const __attribute__((address_space(4))) unsigned *)yv;\n"
+         "    (void)Y; (void)yv; (void)yw; (void)tex;\n";
+    for (uint32_t j = 0; j < E.guard_words; j++)
+        s += "    mr_mask gr" + std::to_string(j) + " = mr_uniform64(mr_gq[" + std::to_string(j) + "]);\n";
+    s += "    for (unsigned t = 0; t < tiles; t++) {\n"
+         "    const unsigned x0 = (blockIdx.x * tiles + t) * 256u;\n"
+         "    if (x0 >= w) break;\n"
+         "/*MR_KBASE*/";
+    for (uint32_t j = 0; j < E.guard_words; j++) {      // opaque per trip as well: 100+ hoisted bit tests would live in SGPRs across the loop
+        const std::string k = std::to_string(j);
+        s += "    asm volatile(\"\" : \"+s\"(gr" + k + "));\n    const mr_mask gq" + k + " = gr" + k + ";\n";
+    }
+    s += "    const unsigned x = x0 + threadIdx.x;\n"
+         "    const double X = (double)x;\n"
          "    double o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"
          "    float mr_defer = 0.0f;                     // fused Step(Sin) ops count their undecided cases in here\n"
-         "    (void)X; (void)Y; (void)yv; (void)yw; (void)tex; (void)gwords;\n/*MR_KBASE*/";
-    if (E.guard_words) {
-        s += "    const __attribute__((address_space(4))) unsigned *gk = (const __attribute__((address_space(4))) unsigned *)(gwords + (size_t)r * " +
-             std::to_string(E.guard_words) + "u);\n";
-        for (uint32_t j = 0; j < E.guard_words; j++) s += "    const unsigned gw" + std::to_string(j) + " = gk[" + std::to_string(j) + "];\n";
-    }
+         "    (void)X; (void)mr_defer;\n";
     if (!E.ignore_row_guards) {         // dry run: which ops yield lane masks
         Emitter D(P);
         D.yv_name = E.yv_name;
@@ -425,13 +504,15 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
             tab += "\n};\n";
         }
         s.replace(s.find("/*MR_KTAB*/"), 11, tab);
-        // the table's address, made opaque: left visible, the compiler re-derives it (s_getpc + s_add + s_addc) at every load
-        s.replace(s.find("/*MR_KBASE*/"), 12, E.ktab_vals.empty() ? "" :
+        // The table's address, made opaque: left visible, the compiler re-derives it (s_getpc + s_add + s_addc) at every
+        // load.  Opaque anew in every trip of the tile loop, and a compiler barrier for LDS: otherwise every constant
+        // and y value is loop-invariant, gets hoisted out of the loop and lives (spills) across it.
+        s.replace(s.find("/*MR_KBASE*/"), 12, E.ktab_vals.empty() ? "    asm volatile(\"\" ::: \"memory\");\n" :
                   "    unsigned long long mr_kbase = (unsigned long long)mr_kc_tab;\n"
-                  "    asm volatile(\"\" : \"+s\"(mr_kbase));\n"
+                  "    asm volatile(\"\" : \"+s\"(mr_kbase) :: \"memory\");\n"
                   "    const mr_kptr mr_kc = (mr_kptr)mr_kbase;\n");
     }
-    s += "    if (mr_defer != 0.0f && x < w) mr_slow_tile = 1u;\n";
+    if (defer) s += "    if (mr_defer != 0.0f && x < w) mr_slow_tile = 1u;\n";
     s += "    if (x < w) {\n"
          "        const size_t p = ((size_t)r * w + x) * 3;\n"
          "        if (rgb64) { rgb64[p] = o0; rgb64[p + 1] = o1; rgb64[p + 2] = o2; }\n"
@@ -441,9 +522,11 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
          "            rgb8[p + 2] = (unsigned char)mr_cast_u8(o2);\n"
          "        }\n"
          "    }\n"
-         "    __syncthreads();\n"
-         "    if (threadIdx.x == 0 && mr_slow_tile) tile_list[1u + atomicAdd(&tile_list[0], 1u)] = tile_base + r * gridDim.x + blockIdx.x;\n"
-         "}\n";
+         "    }\n";
+    if (defer)
+        s += "    __syncthreads();\n"
+             "    if (threadIdx.x == 0 && mr_slow_tile) tile_list[1u + atomicAdd(&tile_list[0], 1u)] = tile_base + r * gridDim.x + blockIdx.x;\n";
+    s += "    (void)tile_list; (void)tile_base;\n}\n";
     return s;
 }
 
@@ -495,15 +578,13 @@ struct JitBackend final : Backend {
     hipFunction_t f_rows = nullptr, f_pix = nullptr;
     Backend *slow = nullptr;            // tape interpreter: evaluates the tiles the pixel kernel deferred
     unsigned *d_flags = nullptr; size_t flags_cap = 0;
-    hipFunction_t f_pack = nullptr;
-    unsigned *d_gwords = nullptr; size_t gwords_cap = 0;
-    uint32_t guard_first = 0, n_guards = 0, n_gwords = 0;
     DevTex *d_tex = nullptr;
     std::vector<unsigned char *> d_tex_rgb;
     double *d_yvals = nullptr; size_t yvals_cap = 0;
     unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;
     double *d_rgb64 = nullptr; size_t rgb64_cap = 0;
     hipStream_t own_stream = nullptr;
+    uint32_t n_row_chunks = 1;
     bool has_sin = false;               // some Sin argument is not proven bounded: tiles may be deferred to `slow`
 
     ~JitBackend() override {
@@ -512,7 +593,6 @@ struct JitBackend final : Backend {
         if (mod) (void)hipModuleUnload(mod);
         if (mod_rows) (void)hipModuleUnload(mod_rows);
         (void)hipFree(d_flags);
-        (void)hipFree(d_gwords);
         (void)hipFree(d_tex);
         for (auto p : d_tex_rgb) (void)hipFree(p);
         (void)hipFree(d_yvals); (void)hipFree(d_rgb8); (void)hipFree(d_rgb64);
@@ -527,13 +607,6 @@ struct JitBackend final : Backend {
         if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
             throw Error{MARAY_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only"};
         has_sin = may_defer_tiles(prog);
-        {   // y values that are only SKIP guards form the tail of the table (see jit_source)
-            const uint32_t n_ynum = numeric_yvals(prog);
-            guard_first = n_ynum;
-            n_guards = prog.n_yvals - n_ynum;
-            n_gwords = (n_guards + 31) / 32;
-            if (n_gwords > 24 || !jit_row_guards_enabled()) n_gwords = 0;   // not used, or too many for SGPRs (the kernel then reads those y values directly)
-        }
         std::vector<char> code, code_rows;
         std::string log;
         // Occupancy: the highest of 8 / 6 / 4 waves per SIMD (<= 64 / 80 / 128 VGPRs) whose build needs no scratch:
@@ -549,14 +622,13 @@ struct JitBackend final : Backend {
             HIP_TRY(hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f_pix));
             if (scratch == 0 || getenv("MARAY_JIT_WAVES")) break;
         }
-        if (prog.n_row_ops) jit_compile(jit_source_rows(prog), code_rows, log);
+        if (prog.n_row_ops) jit_compile(jit_source_rows(prog, &n_row_chunks), code_rows, log);
         slow = make_tape_backend(dev, prog, tex, n_tex, false);
         P = prog;
         P.consts = nullptr; P.row_ops = nullptr; P.pix_ops = nullptr;
         if (prog.n_row_ops) {
             HIP_TRY(hipModuleLoadData(&mod_rows, code_rows.data()));
             HIP_TRY(hipModuleGetFunction(&f_rows, mod_rows, "maray_jit_rows"));
-            HIP_TRY(hipModuleGetFunction(&f_pack, mod_rows, "maray_jit_pack"));
         }
         HIP_TRY(hipStreamCreate(&own_stream));
         std::vector<DevTex> descs(n_tex ? n_tex : 1);
@@ -585,20 +657,19 @@ struct JitBackend final : Backend {
         const uint32_t rows_total = y1 - y0;
         if (!rows_total || !w) return;
         ensure(d_yvals, yvals_cap, (size_t)rows_total * std::max<uint32_t>(P.n_yvals, 1));
-        ensure(d_gwords, gwords_cap, (size_t)rows_total * std::max<uint32_t>(n_gwords, 1));
         unsigned n_yvals = P.n_yvals;
         if (rows_pass && P.n_row_ops) {
             unsigned yy0 = y0, rr = rows_total, ww = w;
             void *args[] = {&d_yvals, &d_tex, &yy0, &rr, &n_yvals, &ww};
-            HIP_TRY(hipModuleLaunchKernel(f_rows, (rows_total + 255) / 256, 1, 1, 256, 1, 1, 0, st, args, nullptr));
-            if (n_gwords) {
-                unsigned first = guard_first, ng = n_guards, nw = n_gwords;
-                void *pargs[] = {&d_yvals, &d_gwords, &rr, &n_yvals, &first, &ng, &nw};
-                HIP_TRY(hipModuleLaunchKernel(f_pack, (rows_total * n_gwords + 255) / 256, 1, 1, 256, 1, 1, 0, st, pargs, nullptr));
-            }
+            HIP_TRY(hipModuleLaunchKernel(f_rows, (rows_total + 63) / 64, n_row_chunks, 1, 64, 1, 1, 0, st, args, nullptr));
         }
-        const unsigned gx = (w + 255) / 256;
-        const uint64_t n_tiles = (uint64_t)gx * rows_total;
+        const unsigned n_tx = (w + 255) / 256;
+        const uint64_t n_tiles = (uint64_t)n_tx * rows_total;
+        // tiles per block: amortise the per-block prologue while leaving >= 16 blocks per CU to balance the tail
+        // (chess @4096^2, tiles = 1 / 2 / 4 / 8 / 16: 0.385 / 0.366 / 0.353 / 0.354 / 0.340 ms)
+        unsigned tiles = has_sin ? 1u : (unsigned)std::min<uint64_t>(std::min<uint64_t>(16, n_tx), std::max<uint64_t>(1, n_tiles / 4096));
+        if (const char *e_ = getenv("MARAY_JIT_TILES")) if (!has_sin && atoi(e_) > 0) tiles = (unsigned)atoi(e_);      // tuning knob
+        const unsigned gx = (n_tx + tiles - 1) / tiles;
         if (n_tiles > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
         ensure(d_flags, flags_cap, (size_t)n_tiles + 1);                    // work list {count, tile, ...} of deferred tiles
         if (has_sin) HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(unsigned), st));
@@ -608,9 +679,8 @@ struct JitBackend final : Backend {
             double *p64 = d64 ? d64 + (size_t)r0 * w * 3 : nullptr;
             const double *yv = d_yvals + (size_t)r0 * n_yvals;
             unsigned *fl = d_flags;
-            const unsigned *gwp = d_gwords + (size_t)r0 * n_gwords;
             unsigned ww = w, yy0 = y0 + r0, tile_base = r0 * gx;
-            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &gwp, &ww, &yy0, &n_yvals};
+            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &ww, &yy0, &n_yvals, &tiles};
             HIP_TRY(hipModuleLaunchKernel(f_pix, gx, rows, 1, 256, 1, 1, 0, st, args, nullptr));
         }
         if (has_sin) slow->render_flagged(w, y0, y1, d8, d64, st, d_flags, d_yvals);   // no-op unless a tile was deferred
