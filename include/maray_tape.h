@@ -32,7 +32,12 @@
  *   kind 2 YVAL   yv[index] of the current row (PIXEL section only)
  *   kind 3 SPEC   index 0 = X (pixel x as f64), 1 = Y (row y as f64),
  *                 2 = ACC (result of the immediately preceding op),
- *                 3 = XMAX (ROW section only: (w - 1) as f64, the x of a row's last pixel)
+ *                 3 = XMAX, 4 = XMIN (ROW section only): the largest and the smallest x, as f64, of the
+ *                 span of pixels that the row's SKIP guards are being evaluated for.  Only y values
+ *                 that gate SKIP ops depend on them (they bound a boolean over the span: guard == 0
+ *                 proves the boolean 0 for every x in [XMIN, XMAX]); y values read as operands never
+ *                 do.  An evaluator that runs the ROW section once per row passes 0 and w - 1; one
+ *                 that evaluates the guards per tile of a row passes the tile's ends and skips more.
  *
  * Every op also leaves its result in ACC.  An op with dst == MARAY_DST_NONE
  * is consumed only through ACC by the next op.
@@ -42,7 +47,7 @@
 
 #include <stdint.h>
 
-#define MARAY_TAPE_VERSION 1u
+#define MARAY_TAPE_VERSION 2u   /* 2: SPEC XMIN */
 
 enum {
     MARAY_OP_NOP = 0,
@@ -86,7 +91,7 @@ enum {
 #define MARAY_MAX_INDEX 0x3FFFu
 
 enum { MARAY_K_SLOT = 0, MARAY_K_CONST = 1, MARAY_K_YVAL = 2, MARAY_K_SPEC = 3 };
-enum { MARAY_SPEC_X = 0, MARAY_SPEC_Y = 1, MARAY_SPEC_ACC = 2, MARAY_SPEC_XMAX = 3 };
+enum { MARAY_SPEC_X = 0, MARAY_SPEC_Y = 1, MARAY_SPEC_ACC = 2, MARAY_SPEC_XMAX = 3, MARAY_SPEC_XMIN = 4 };
 
 #define MARAY_REF(kind, index) ((uint32_t)(((kind) << 14) | ((index) & 0x3FFFu)))
 #define MARAY_REF_KIND(r) (((r) >> 14) & 3u)

@@ -76,7 +76,8 @@ __device__ __forceinline__ void run_tape(const KArgs &A, const uint64_t *tape_ld
         if (kind == MARAY_K_SLOT) return idx < n_lds ? slots[idx * BLOCK + tid] : spill_base[(size_t)(idx - n_lds) * spill_stride];
         if (kind == MARAY_K_CONST) return TAPE_LDS ? consts_lds[idx] : consts_k[idx];
         if (kind == MARAY_K_YVAL) return yrow_k[idx];
-        return idx == MARAY_SPEC_X ? X : (idx == MARAY_SPEC_Y ? Y : (idx == MARAY_SPEC_ACC ? acc : (double)(A.w - 1u)));
+        // guards are evaluated once per row here: the span is the whole row, XMIN = 0 and XMAX = w - 1
+        return idx == MARAY_SPEC_X ? X : (idx == MARAY_SPEC_Y ? Y : (idx == MARAY_SPEC_ACC ? acc : (idx == MARAY_SPEC_XMAX ? (double)(A.w - 1u) : 0.0)));
     };
 
     for (uint32_t pc = 0; pc < A.n_ops; ++pc) {

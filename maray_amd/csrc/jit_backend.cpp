@@ -117,6 +117,7 @@ struct Emitter {
     // order the code reads them (one entry per use, shared inside a basic block): the compiler then fetches a block's
     // constants with a few s_load_dwordx4/x8/x16 instead of two s_mov_b32 per use, and the scalar unit -- which also
     // does all the boolean algebra and every region's branch -- is what bounds this kernel.
+    bool out_guard_bits = false;                 // ROW-section OUT of a guard (index >= guard_first): OR its bit into `gacc`
     bool ktab = false;
     std::vector<double> ktab_vals;
     std::unordered_map<uint64_t, uint32_t> ktab_block;
@@ -154,7 +155,7 @@ struct Emitter {
             case MARAY_K_YVAL: t.d = yv_name + "[" + std::to_string(idx) + "]"; return &t;
             default:
                 if (idx == MARAY_SPEC_ACC) return &vals[acc];
-                t.d = idx == MARAY_SPEC_X ? "X" : (idx == MARAY_SPEC_Y ? "Y" : "XMAX");
+                t.d = idx == MARAY_SPEC_X ? "X" : (idx == MARAY_SPEC_Y ? "Y" : (idx == MARAY_SPEC_XMAX ? "XMAX" : "XMIN"));
                 return &t;
             }
         };
@@ -215,8 +216,11 @@ struct Emitter {
             }
             if (op == MARAY_OP_OUT) {
                 const std::string a = dbl(va, "m", i, 0);
-                out += pixel ? "    o" + std::to_string(aux) + " = " + a + ";\n"
-                             : "    yout[" + std::to_string(aux) + "] = " + a + ";\n";
+                if (!pixel && out_guard_bits && aux >= guard_first)
+                    out += "    gacc |= (" + a + " != 0.0) ? (1ull << " + std::to_string((aux - guard_first) % 64) + ") : 0ull;\n";
+                else
+                    out += pixel ? "    o" + std::to_string(aux) + " = " + a + ";\n"
+                                 : "    yout[" + std::to_string(aux) + "] = " + a + ";\n";
                 continue;
             }
             Val *vb = (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) ? ref(MARAY_INS_B(ins), 1) : nullptr;
@@ -314,12 +318,17 @@ struct Emitter {
 // values are independent outputs, so the tape is cut by outputs: chunk k keeps the ops its outputs
 // depend on (ops two chunks share are computed in both) and the rest become NOPs.  SKIP ops are
 // dropped -- legal for any evaluator, and 64 different rows rarely agree anyway.
-std::vector<std::vector<uint64_t>> split_row_tape(const maray_program &P, uint32_t out_limit)
+struct RowTapeDeps {
+    std::vector<std::array<int32_t, 2>> deps;   // per op: the ops that produce its operands (-1: none)
+    std::vector<uint32_t> outs;                 // OUT ops, tape order
+};
+
+RowTapeDeps row_tape_deps(const maray_program &P)
 {
     const uint32_t n = P.n_row_ops;
-    std::vector<std::array<int32_t, 2>> deps(n, {-1, -1});
+    RowTapeDeps d;
+    d.deps.assign(n, {-1, -1});
     std::vector<int32_t> slot_writer(P.n_row_slots ? P.n_row_slots : 1, -1);
-    std::vector<uint32_t> outs;
     int32_t acc = -1;
     auto producer = [&](uint32_t ref) -> int32_t {
         const uint32_t kind = MARAY_REF_KIND(ref), idx = MARAY_REF_INDEX(ref);
@@ -331,61 +340,96 @@ std::vector<std::vector<uint64_t>> split_row_tape(const maray_program &P, uint32
         const uint64_t ins = P.row_ops[j];
         const uint32_t op = MARAY_INS_OP(ins);
         if (op == MARAY_OP_NOP || op == MARAY_OP_SKIPZ || op == MARAY_OP_SKIPNZ) continue;
-        if (op != MARAY_OP_TEXDIM) deps[j][0] = producer(MARAY_INS_A(ins));
-        if (op == MARAY_OP_OUT) { if (MARAY_INS_AUX(ins) < out_limit) outs.push_back(j); continue; }
-        if (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) deps[j][1] = producer(MARAY_INS_B(ins));
+        if (op != MARAY_OP_TEXDIM) d.deps[j][0] = producer(MARAY_INS_A(ins));
+        if (op == MARAY_OP_OUT) { d.outs.push_back(j); continue; }
+        if (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) d.deps[j][1] = producer(MARAY_INS_B(ins));
         acc = (int32_t)j;
         if (MARAY_INS_DST(ins) != MARAY_DST_NONE) slot_writer[MARAY_INS_DST(ins)] = (int32_t)j;
     }
-    const uint32_t n_chunks = std::min<uint32_t>(16, std::max<uint32_t>(1, n / 640));
+    return d;
+}
+
+// The ROW tape with everything but the cone of the given OUT ops turned into NOPs.
+std::vector<uint64_t> row_tape_cone(const maray_program &P, const RowTapeDeps &d, const std::vector<uint32_t> &outs, size_t *cost)
+{
+    std::vector<uint64_t> tape(P.n_row_ops, 0);           // 0 = NOP
+    std::vector<int32_t> st(outs.begin(), outs.end());
+    size_t c = 0;
+    while (!st.empty()) {
+        const int32_t v = st.back(); st.pop_back();
+        if (v < 0 || tape[v]) continue;
+        tape[v] = P.row_ops[v];
+        c++;
+        st.push_back(d.deps[v][0]); st.push_back(d.deps[v][1]);
+    }
+    if (cost) *cost = c;
+    return tape;
+}
+
+std::vector<std::vector<uint64_t>> split_row_tape(const maray_program &P, const RowTapeDeps &d, uint32_t out_limit)
+{
+    const uint32_t n = P.n_row_ops;
+    std::vector<uint32_t> outs;
+    for (uint32_t j : d.outs) if (MARAY_INS_AUX(P.row_ops[j]) < out_limit) outs.push_back(j);
+    size_t total = 0;
+    (void)row_tape_cone(P, d, outs, &total);
+    const uint32_t n_chunks = (uint32_t)std::min<size_t>(16, std::max<size_t>(1, total / 256));
+    const size_t budget = (total + n_chunks - 1) / n_chunks;
     std::vector<std::vector<uint64_t>> chunks;
-    std::vector<uint32_t> stamp(n, 0);
-    std::vector<int32_t> st;
     size_t next = 0;
-    for (uint32_t k = 1; next < outs.size(); k++) {
-        std::vector<uint64_t> tape(n, 0);           // 0 = NOP
-        const size_t budget = (n + n_chunks - 1) / n_chunks;
+    while (next < outs.size()) {
+        std::vector<uint32_t> mine;
         size_t cost = 0;
+        std::vector<uint64_t> tape;
         while (next < outs.size() && (cost < budget || chunks.size() + 1 == n_chunks)) {
-            st.push_back((int32_t)outs[next++]);
-            while (!st.empty()) {
-                const int32_t v = st.back(); st.pop_back();
-                if (v < 0 || stamp[v] == k) continue;
-                stamp[v] = k;
-                tape[v] = P.row_ops[v];
-                cost++;
-                st.push_back(deps[v][0]); st.push_back(deps[v][1]);
-            }
+            mine.push_back(outs[next++]);
+            if (chunks.size() + 1 == n_chunks) continue;        // the last chunk takes the rest: one cone at the end
+            tape = row_tape_cone(P, d, mine, &cost);
         }
-        chunks.push_back(std::move(tape));
+        chunks.push_back(row_tape_cone(P, d, mine, &cost));
     }
     if (chunks.empty()) chunks.emplace_back(n, 0);
     return chunks;
 }
 
-// Source of the ROW kernel: one work-item per row, one wavefront per block, blockIdx.y = chunk of
-// the ROW section.  Plain device_math.h: the rare huge-argument tail of sin is a real (out-of-line)
-// call here.
+// How the specialised kernels use the row guards of a program: as bits, 64 per word, one set per
+// 256-pixel tile of a row (guard_words = 0: not at all -- none, too many, or switched off).
+uint32_t jit_guard_words(const maray_program &P)
+{
+    const uint32_t n_guards = P.n_yvals - numeric_yvals(P);
+    const uint32_t nw = (n_guards + 63) / 64;
+    return (jit_row_guards_enabled() && nw <= 12) ? nw : 0;
+}
+
+// Source of the ROW kernels.
+//  maray_jit_rows: one work-item per row, one wavefront per block, blockIdx.y = chunk of the ROW
+//    section; writes the y values the pixel kernel reads as operands (and, for a program that may
+//    defer tiles to the interpreter, the guards too, bounded over the whole row as it expects).
+//  maray_jit_guards: the guard outputs, evaluated once per 256-pixel tile of every row with
+//    XMIN / XMAX = the tile's ends (a bound over 256 pixels skips far more than one over the
+//    row), one work-item per (row, tile), blockIdx.y = guard word; writes 64 guards as one word.
+// Plain device_math.h: the rare huge-argument tail of sin is a real (out-of-line) call here.
 std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out)
 {
     validate_program(P);
     Emitter E(P);
+    const RowTapeDeps deps = row_tape_deps(P);
+    const uint32_t n_ynum = numeric_yvals(P), n_gwords = jit_guard_words(P);
     // the interpreter (which drains deferred tiles from the same y-value table) does read the guard values
-    uint32_t out_limit = 0xFFFFFFFFu;
-    if (!jit_row_guards_enabled() && !may_defer_tiles(P)) out_limit = numeric_yvals(P);
-    const std::vector<std::vector<uint64_t>> chunks = split_row_tape(P, out_limit);
+    const uint32_t out_limit = may_defer_tiles(P) ? 0xFFFFFFFFu : n_ynum;
+    const std::vector<std::vector<uint64_t>> chunks = split_row_tape(P, deps, out_limit);
     if (n_chunks_out) *n_chunks_out = (uint32_t)chunks.size();
     std::string &s = E.out;
-    s += "// generated by libmaray_hip (jit_backend.cpp): ROW section, " + std::to_string(P.n_row_ops) + " ops in " +
-         std::to_string(chunks.size()) + " chunks\n";
+    s += "// generated by libmaray_hip (jit_backend.cpp): ROW section, " + std::to_string(P.n_row_ops) + " ops; y values in " +
+         std::to_string(chunks.size()) + " chunks, " + std::to_string(P.n_yvals - n_ynum) + " guards in " + std::to_string(n_gwords) + " words\n";
     s += "#include \"device_math.h\"\n\n";
     s += "extern \"C\" __global__ void __launch_bounds__(64) maray_jit_rows(double *__restrict__ yvals, const MarayTex *__restrict__ tex,\n"
          "                                                                 unsigned y0, unsigned rows, unsigned n_yvals, unsigned w)\n{\n"
          "    const unsigned r = blockIdx.x * 64u + threadIdx.x;\n"
          "    if (r >= rows) return;\n"
-         "    const double Y = (double)(y0 + r), XMAX = (double)(w - 1u);\n"
+         "    const double Y = (double)(y0 + r), XMIN = 0.0, XMAX = (double)(w - 1u);\n"
          "    double *yout = yvals + (size_t)r * n_yvals;\n"
-         "    (void)Y; (void)XMAX; (void)tex; (void)yout;\n"
+         "    (void)Y; (void)XMIN; (void)XMAX; (void)tex; (void)yout;\n"
          "    switch (blockIdx.y) {\n";
     for (size_t k = 0; k < chunks.size(); k++) {
         s += "    case " + std::to_string(k) + ": {\n";
@@ -393,6 +437,34 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out)
         s += "    } break;\n";
     }
     s += "    }\n}\n\n";
+    if (n_gwords) {
+        s += "extern \"C\" __global__ void __launch_bounds__(64) maray_jit_guards(unsigned long long *__restrict__ gbits, const MarayTex *__restrict__ tex,\n"
+             "                                                                   unsigned y0, unsigned rows, unsigned w, unsigned n_tx)\n{\n"
+             "    const unsigned long long item = (unsigned long long)blockIdx.x * 64u + threadIdx.x;      // (row, tile), tiles of a row adjacent\n"
+             "    if (item >= (unsigned long long)rows * n_tx) return;\n"
+             "    const unsigned r = (unsigned)(item / n_tx), tile = (unsigned)(item % n_tx);\n"
+             "    const unsigned xlo = tile * 256u, xhi = xlo + 255u < w - 1u ? xlo + 255u : w - 1u;\n"
+             "    const double Y = (double)(y0 + r), XMIN = (double)xlo, XMAX = (double)xhi;\n"
+             "    unsigned long long gacc = 0ull;\n"
+             "    double *yout = nullptr;\n"
+             "    (void)Y; (void)XMIN; (void)XMAX; (void)tex; (void)yout;\n"
+             "    switch (blockIdx.y) {\n";
+        E.out_guard_bits = true;
+        E.guard_first = n_ynum;
+        for (uint32_t j = 0; j < n_gwords; j++) {
+            std::vector<uint32_t> outs;
+            for (uint32_t o : deps.outs) {
+                const uint32_t aux = MARAY_INS_AUX(P.row_ops[o]);
+                if (aux >= n_ynum + 64 * j && aux < n_ynum + 64 * (j + 1)) outs.push_back(o);
+            }
+            const std::vector<uint64_t> tape = row_tape_cone(P, deps, outs, nullptr);
+            s += "    case " + std::to_string(j) + ": {\n";
+            E.section(tape.data(), P.n_row_ops, P.n_row_slots, false, "r");
+            s += "    } break;\n";
+        }
+        s += "    }\n"
+             "    gbits[item * " + std::to_string(n_gwords) + "u + blockIdx.y] = gacc;\n}\n";
+    }
     return s;
 }
 
@@ -417,16 +489,15 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
     const int min_waves = env_waves ? atoi(env_waves) : min_waves_arg;
     const uint32_t n_ynum = numeric_yvals(P);   // y values read as operands (a prefix of the table); the rest only gate SKIPs
     const bool y_lds = n_ynum > 0 && n_ynum <= 4096 && !(env_ylds && env_ylds[0] == '0');
-    const uint32_t n_guards = P.n_yvals - n_ynum;
-    const uint32_t n_gwords = (n_guards + 63) / 64;
-    // Row-level SKIP ops (guard = a y value that bounds a boolean over the whole row): the block's prologue turns the
-    // row's guard values into bits (one coalesced load + ballot per 256 guards), 64 per word, and every wave keeps the
-    // words in SGPRs; a region's test is then one s_bitcmp1_b64.  MARAY_JIT_ROW_GUARDS=0 compiles them away.
-    E.ignore_row_guards = !jit_row_guards_enabled();
-    if (!E.ignore_row_guards && n_gwords > 0 && n_gwords <= 12) { E.guard_first = n_ynum; E.guard_words = n_gwords; }
+    // Row-level SKIP ops (guard = a y value that bounds a boolean over a span of the row): maray_jit_guards has
+    // evaluated them for every 256-pixel tile and packed them 64 per word; the words of the tile at hand sit in SGPRs
+    // (one scalar load per trip of the tile loop) and a region's test is one s_bitcmp1_b64.  Without usable guard
+    // words (none, too many, or MARAY_JIT_ROW_GUARDS=0) those SKIP ops are compiled away.
+    const uint32_t n_gwords = jit_guard_words(P);
+    E.ignore_row_guards = n_gwords == 0;
+    if (n_gwords) { E.guard_first = n_ynum; E.guard_words = n_gwords; }
     if (y_lds) E.yv_name = "mr_ylds";
     if (y_lds) s += "__shared__ double mr_ylds[" + std::to_string(n_ynum) + "];\n";
-    if (E.guard_words) s += "__shared__ unsigned long long mr_gq[" + std::to_string(E.guard_words) + "];\n";
     const bool defer = may_defer_tiles(P);
     s += "__shared__ unsigned mr_slow_tile;\n"
          "__device__ inline double mr_defer_sin(double) { mr_slow_tile = 1u; return 0.0; }\n"
@@ -440,44 +511,34 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
          ") maray_jit_pixels(unsigned char *__restrict__ rgb8, double *__restrict__ rgb64,\n"
          "                                                                    const double *__restrict__ yvals, const MarayTex *__restrict__ tex,\n"
          "                                                                    unsigned *__restrict__ tile_list, unsigned tile_base,\n"
+         "                                                                    const unsigned long long *__restrict__ gbits, unsigned n_tx,\n"
          "                                                                    unsigned w, unsigned y0, unsigned n_yvals, unsigned tiles)\n{\n"
          "    const unsigned r = blockIdx.y;\n"
          "    const double *yrow = yvals + (size_t)r * n_yvals;\n";
     if (defer) s += "    if (threadIdx.x == 0) mr_slow_tile = 0u;\n";
     // every load of the prologue is issued before the first use: one memory latency, not one per round
-    const uint32_t y_rounds = y_lds ? (n_ynum + 255) / 256 : 0, g_rounds = (E.guard_words * 64 + 255) / 256;
+    const uint32_t y_rounds = y_lds ? (n_ynum + 255) / 256 : 0;
     for (uint32_t k = 0; k < y_rounds; k++) {
         const std::string i = std::to_string(k * 256) + "u + threadIdx.x";
         s += "    const double ys" + std::to_string(k) + " = " + i + " < " + std::to_string(n_ynum) + "u ? yrow[" + i + "] : 0.0;\n";
-    }
-    for (uint32_t k = 0; k < g_rounds; k++) {       // guard values -> bits: lane i of round k owns guard 256 k + i
-        const std::string i = std::to_string(k * 256) + "u + threadIdx.x";
-        s += "    const double gs" + std::to_string(k) + " = " + i + " < " + std::to_string(n_guards) + "u ? yrow[" +
-             std::to_string(n_ynum) + "u + " + i + "] : 0.0;\n";
     }
     for (uint32_t k = 0; k < y_rounds; k++) {
         const std::string i = std::to_string(k * 256) + "u + threadIdx.x";
         s += "    if (" + i + " < " + std::to_string(n_ynum) + "u) mr_ylds[" + i + "] = ys" + std::to_string(k) + ";\n";
     }
-    for (uint32_t k = 0; k < g_rounds; k++) {
-        const std::string i = "(" + std::to_string(k * 256) + "u + threadIdx.x)";
-        s += "    {\n        const mr_mask gm = mr_ballot(gs" + std::to_string(k) + " != 0.0);\n"
-             "        if ((threadIdx.x & 63u) == 0u && " + i + " < " + std::to_string(E.guard_words * 64) + "u) mr_gq[" + i + " >> 6] = gm;\n    }\n";
-    }
     s += "    __syncthreads();\n"
          "    const double Y = (double)(y0 + r);\n"
          "    mr_kptr yv = (mr_kptr)yrow;\n"
          "    const __attribute__((address_space(4))) unsigned *yw = (const __attribute__((address_space(4))) unsigned *)yv;\n"
-         "    (void)Y; (void)yv; (void)yw; (void)tex;\n";
-    for (uint32_t j = 0; j < E.guard_words; j++)
-        s += "    mr_mask gr" + std::to_string(j) + " = mr_uniform64(mr_gq[" + std::to_string(j) + "]);\n";
+         "    (void)Y; (void)yv; (void)yw; (void)tex; (void)gbits; (void)n_tx;\n";
     s += "    for (unsigned t = 0; t < tiles; t++) {\n"
          "    const unsigned x0 = (blockIdx.x * tiles + t) * 256u;\n"
          "    if (x0 >= w) break;\n"
          "/*MR_KBASE*/";
-    for (uint32_t j = 0; j < E.guard_words; j++) {      // opaque per trip as well: 100+ hoisted bit tests would live in SGPRs across the loop
-        const std::string k = std::to_string(j);
-        s += "    asm volatile(\"\" : \"+s\"(gr" + k + "));\n    const mr_mask gq" + k + " = gr" + k + ";\n";
+    if (E.guard_words) {
+        s += "    const __attribute__((address_space(4))) unsigned long long *gk = (const __attribute__((address_space(4))) unsigned long long *)\n"
+             "        (gbits + ((size_t)r * n_tx + (blockIdx.x * tiles + t)) * " + std::to_string(E.guard_words) + "u);\n";
+        for (uint32_t j = 0; j < E.guard_words; j++) s += "    const mr_mask gq" + std::to_string(j) + " = gk[" + std::to_string(j) + "];\n";
     }
     s += "    const unsigned x = x0 + threadIdx.x;\n"
          "    const double X = (double)x;\n"
@@ -584,7 +645,9 @@ struct JitBackend final : Backend {
     unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;
     double *d_rgb64 = nullptr; size_t rgb64_cap = 0;
     hipStream_t own_stream = nullptr;
-    uint32_t n_row_chunks = 1;
+    uint32_t n_row_chunks = 1, n_gwords = 0;
+    hipFunction_t f_guards = nullptr;
+    unsigned long long *d_gbits = nullptr; size_t gbits_cap = 0;
     bool has_sin = false;               // some Sin argument is not proven bounded: tiles may be deferred to `slow`
 
     ~JitBackend() override {
@@ -595,6 +658,7 @@ struct JitBackend final : Backend {
         (void)hipFree(d_flags);
         (void)hipFree(d_tex);
         for (auto p : d_tex_rgb) (void)hipFree(p);
+        (void)hipFree(d_gbits);
         (void)hipFree(d_yvals); (void)hipFree(d_rgb8); (void)hipFree(d_rgb64);
         if (own_stream) (void)hipStreamDestroy(own_stream);
     }
@@ -629,6 +693,8 @@ struct JitBackend final : Backend {
         if (prog.n_row_ops) {
             HIP_TRY(hipModuleLoadData(&mod_rows, code_rows.data()));
             HIP_TRY(hipModuleGetFunction(&f_rows, mod_rows, "maray_jit_rows"));
+            n_gwords = jit_guard_words(prog);
+            if (n_gwords) HIP_TRY(hipModuleGetFunction(&f_guards, mod_rows, "maray_jit_guards"));
         }
         HIP_TRY(hipStreamCreate(&own_stream));
         std::vector<DevTex> descs(n_tex ? n_tex : 1);
@@ -657,11 +723,19 @@ struct JitBackend final : Backend {
         const uint32_t rows_total = y1 - y0;
         if (!rows_total || !w) return;
         ensure(d_yvals, yvals_cap, (size_t)rows_total * std::max<uint32_t>(P.n_yvals, 1));
+        ensure(d_gbits, gbits_cap, (size_t)rows_total * ((w + 255) / 256) * std::max<uint32_t>(n_gwords, 1));
         unsigned n_yvals = P.n_yvals;
         if (rows_pass && P.n_row_ops) {
             unsigned yy0 = y0, rr = rows_total, ww = w;
             void *args[] = {&d_yvals, &d_tex, &yy0, &rr, &n_yvals, &ww};
             HIP_TRY(hipModuleLaunchKernel(f_rows, (rows_total + 63) / 64, n_row_chunks, 1, 64, 1, 1, 0, st, args, nullptr));
+            if (n_gwords) {         // the guards of every (row, 256-pixel tile)
+                unsigned n_tx_ = (w + 255) / 256;
+                const uint64_t items = (uint64_t)rows_total * n_tx_;
+                if ((items + 63) / 64 > 0x7FFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
+                void *gargs[] = {&d_gbits, &d_tex, &yy0, &rr, &ww, &n_tx_};
+                HIP_TRY(hipModuleLaunchKernel(f_guards, (unsigned)((items + 63) / 64), n_gwords, 1, 64, 1, 1, 0, st, gargs, nullptr));
+            }
         }
         const unsigned n_tx = (w + 255) / 256;
         const uint64_t n_tiles = (uint64_t)n_tx * rows_total;
@@ -680,7 +754,9 @@ struct JitBackend final : Backend {
             const double *yv = d_yvals + (size_t)r0 * n_yvals;
             unsigned *fl = d_flags;
             unsigned ww = w, yy0 = y0 + r0, tile_base = r0 * gx;
-            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &ww, &yy0, &n_yvals, &tiles};
+            const unsigned long long *gb = d_gbits + (size_t)r0 * n_tx * n_gwords;
+            unsigned ntx = n_tx;
+            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles};
             HIP_TRY(hipModuleLaunchKernel(f_pix, gx, rows, 1, 256, 1, 1, 0, st, args, nullptr));
         }
         if (has_sin) slow->render_flagged(w, y0, y1, d8, d64, st, d_flags, d_yvals);   // no-op unless a tile was deferred

@@ -31,7 +31,7 @@ namespace maray {
 
 namespace {
 
-enum : uint8_t { D_CONST = 100, D_X = 101, D_Y = 102, D_XMAX = 103 };   // leaf kinds; ops use MARAY_OP_*  (XMAX = x of a row's last pixel)
+enum : uint8_t { D_CONST = 100, D_X = 101, D_Y = 102, D_XMAX = 103, D_XMIN = 104 };   // leaf kinds; ops use MARAY_OP_*  (XMIN, XMAX: ends of the span of x a guard bounds)
 enum : uint8_t { DEP_X = 1, DEP_Y = 2 };
 
 struct DNode {
@@ -245,7 +245,7 @@ std::vector<Ival> intervals(const Dag &g)
         Ival r{-INFINITY, INFINITY, true};
         switch (d.op) {
         case D_CONST: r = (d.cval != d.cval) ? Ival{-INFINITY, INFINITY, true} : Ival{d.cval, d.cval, false}; break;
-        case D_X: case D_Y: case D_XMAX: r = Ival{0.0, dmax, false}; break;
+        case D_X: case D_Y: case D_XMAX: case D_XMIN: r = Ival{0.0, dmax, false}; break;
         case MARAY_OP_MOV: r = a; break;
         case MARAY_OP_NEG: r = Ival{-a.hi, -a.lo, a.nan}; break;
         case MARAY_OP_ABS:
@@ -331,7 +331,8 @@ std::vector<Mono> monotonicity(const Dag &g, const std::vector<Ival> &iv)
 
 // Builds, for boolean nodes, y-only boolean expressions that bound them over a whole row:
 //   ub(v)(y) == 0  =>  v(x, y) == 0 for every pixel x in [0, w)        (lb: == 1 => v == 1)
-// A monotone boolean takes its extreme values at the row's end points x = 0 and x = w-1 (XMAX).
+// A monotone boolean takes its extreme values at the end points of the span, x = XMIN and x = XMAX
+// (the whole row, 0 and w-1, or any part of it: monotone on the domain is monotone on a sub-interval).
 struct RowBounds {
     Dag &g;
     const std::vector<uint8_t> &isbool;
@@ -341,7 +342,7 @@ struct RowBounds {
     int32_t c_true, c_false, x0, xmax;
 
     RowBounds(Dag &g_, const std::vector<uint8_t> &b, const std::vector<Mono> &m) : g(g_), isbool(b), mono(m) {
-        c_true = g.konst(1.0); c_false = g.konst(0.0); x0 = g.konst(0.0); xmax = g.leaf(D_XMAX);
+        c_true = g.konst(1.0); c_false = g.konst(0.0); x0 = g.leaf(D_XMIN); xmax = g.leaf(D_XMAX);
     }
     int32_t subst(int32_t i, int32_t xr) {          // i with X replaced by node xr
         const DNode d = g.n[i];
@@ -803,6 +804,7 @@ struct Lowerer {
             if (d.op == D_X) return MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_X);
             if (d.op == D_Y) return MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_Y);
             if (d.op == D_XMAX) return MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_XMAX);
+            if (d.op == D_XMIN) return MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_XMIN);
             if (in_section[c]) {
                 if (acc_holder[j] == c) { sec.acc_operands++; return MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_ACC); }
                 if (slot[c] < 0) throw Error{MARAY_E_INTERNAL, "operand without a slot"};

@@ -59,7 +59,7 @@ def _cast_u32(v):
     return np.minimum(v, 4294967295.0).astype(np.uint64)
 
 
-def run_section(ops, consts, n_slots, X, Y, yvals, textures, n_out, honor_skips=False, w=None):
+def run_section(ops, consts, n_slots, X, Y, yvals, textures, n_out, honor_skips=False, w=None, span=None):
     """Evaluate one section for a vector of items.  X, Y: float64 arrays (same
     shape); yvals: array [..., n_yvals] broadcastable per item or None.
     honor_skips: take SKIPZ / SKIPNZ when the whole vector agrees (call per 64-item "wavefront")."""
@@ -73,7 +73,9 @@ def run_section(ops, consts, n_slots, X, Y, yvals, textures, n_out, honor_skips=
         if kind == K_SLOT: return slots[idx]
         if kind == K_CONST: return np.full(shape, consts[idx])
         if kind == K_YVAL: return yvals[..., idx]
-        return X if idx == 0 else (Y if idx == 1 else (acc if idx == 2 else np.full(shape, float(w - 1))))
+        if idx == 3: return np.full(shape, float(span[1] if span else w - 1))      # XMAX
+        if idx == 4: return np.full(shape, float(span[0] if span else 0))          # XMIN
+        return X if idx == 0 else (Y if idx == 1 else acc)
 
     with np.errstate(all='ignore'):
         pc = -1
@@ -126,22 +128,29 @@ def run_section(ops, consts, n_slots, X, Y, yvals, textures, n_out, honor_skips=
     return outs
 
 
-def render_rows_waves(tape, w, y0, y1, textures=None):
+def render_rows_waves(tape, w, y0, y1, textures=None, tile=None):
     """Like render_rows, but wavefront by wavefront (64 consecutive x of one row; the ROW section in
-    groups of 64 rows) with SKIPZ / SKIPNZ honoured the way the device kernels do."""
+    groups of 64 rows) with SKIPZ / SKIPNZ honoured the way the device kernels do.  tile: evaluate
+    the ROW section once per `tile` pixels of a row with XMIN / XMAX = that span (what the
+    specialised kernels do for the guard values) instead of once per row."""
     consts, row_ops, pix_ops = tape.arrays()
     info = tape.info
     rows = y1 - y0
     out = np.zeros((rows, w, 3))
-    yv_all = None
-    if info['n_yvals']:
-        yv_all = np.zeros((rows, info['n_yvals']))
-        for r0 in range(0, rows, 64):
-            ys = np.arange(y0 + r0, min(y1, y0 + r0 + 64), dtype=np.float64)
-            outs = run_section(row_ops, consts, info['n_row_slots'], None, ys, None, textures, info['n_yvals'], True, w=w)
-            yv_all[r0:r0 + len(ys)] = np.stack(outs, axis=-1)
+    spans = [None] if not tile else [(x0, min(w, x0 + tile) - 1) for x0 in range(0, w, tile)]
+    yv_span = []
+    for span in spans:
+        yv_all = None
+        if info['n_yvals']:
+            yv_all = np.zeros((rows, info['n_yvals']))
+            for r0 in range(0, rows, 64):
+                ys = np.arange(y0 + r0, min(y1, y0 + r0 + 64), dtype=np.float64)
+                outs = run_section(row_ops, consts, info['n_row_slots'], None, ys, None, textures, info['n_yvals'], True, w=w, span=span)
+                yv_all[r0:r0 + len(ys)] = np.stack(outs, axis=-1)
+        yv_span.append(yv_all)
     for r in range(rows):
         for x0 in range(0, w, 64):
+            yv_all = yv_span[x0 // tile if tile else 0]
             X = np.arange(x0, x0 + 64, dtype=np.float64)        # lanes beyond w compute too, like on the device
             Y = np.full(64, float(y0 + r))
             yv = np.broadcast_to(yv_all[r][None, :], (64, info['n_yvals'])) if yv_all is not None else None

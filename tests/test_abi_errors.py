@@ -24,7 +24,7 @@ SLOT, CONST, YVAL, SPEC = 0, 1, 2, 3
 X, Y, ACC = ref(SPEC, 0), ref(SPEC, 1), ref(SPEC, 2)
 
 
-def create(pix_ops, n_slots=4, consts=(1.0,), n_yvals=0, n_app=0, row_ops=(), version=1):
+def create(pix_ops, n_slots=4, consts=(1.0,), n_yvals=0, n_app=0, row_ops=(), version=2):
     c = np.array(consts, np.float64)
     po = np.array(pix_ops, np.uint64)
     ro = np.array(row_ops, np.uint64)

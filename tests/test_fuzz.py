@@ -40,6 +40,7 @@ def test_random_scenes_lowering_vs_oracle():
         assert np.array_equal(tape_eval.cast_u8(got), want8), seed
         if tape.info['skip_ops']:
             assert same_f64(tape_eval.render_rows_waves(tape, W, 0, H, t), want64), seed
+            assert same_f64(tape_eval.render_rows_waves(tape, W, 0, H, t, tile=64), want64), seed      # guards per span
         done += 1
     assert done >= 50
 

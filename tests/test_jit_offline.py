@@ -43,8 +43,9 @@ def test_chess_uses_the_pure_bounded_step_sin(chess_bytes):
 
 
 def test_row_section_is_cut_into_chunks(chess_bytes):
-    """The ROW kernel evaluates independent chunks of the ROW section side by side (blockIdx.y); every y value is
-    written by exactly one chunk, and the source builds."""
+    """maray_jit_rows evaluates independent chunks of the ROW section side by side (blockIdx.y): every y value the
+    pixel kernel reads as an operand is written by exactly one chunk.  The guards are not y values here: maray_jit_guards
+    evaluates them per 256-pixel tile (XMIN / XMAX = the tile's ends) and packs them 64 to a word.  Both kernels build."""
     import re
     s = M.Scene(chess_bytes)
     s.rescale(4, 4)
@@ -55,10 +56,13 @@ def test_row_section_is_cut_into_chunks(chess_bytes):
     assert L.maray_jit_source_rows(C.byref(tape.program), C.byref(src), C.byref(k)) == 0, L.maray_last_error()
     text = C.string_at(src).decode()
     L.maray_free(src)
-    assert 2 <= k.value <= 16 and text.count('    case ') == k.value
-    written = sorted(int(m) for m in re.findall(r'yout\[(\d+)\] = ', text))
-    assert written == list(range(tape.info['n_yvals']))
-    # chunks share little: the ops emitted over all chunks stay close to the section's own count
-    emitted = len(re.findall(r'const (?:double|mr_mask) ', text))
-    assert emitted < 1.5 * tape.info['n_row_ops']
-    build(tape)        # compiles the ROW kernel as well
+    rows_src, guards_src = text.split('maray_jit_guards')
+    assert 2 <= k.value <= 16 and rows_src.count('    case ') == k.value
+    written = sorted(int(m) for m in re.findall(r'yout\[(\d+)\] = ', rows_src))
+    n_num = len(written)
+    assert written == list(range(n_num)) and 0 < n_num < tape.info['n_yvals']
+    n_guards = tape.info['n_yvals'] - n_num
+    assert len(re.findall(r'gacc \|= ', guards_src)) == n_guards and 'yout[' not in guards_src.split('switch')[1]
+    assert guards_src.count('    case ') == (n_guards + 63) // 64
+    assert 'XMIN' in guards_src and 'XMIN' not in rows_src.split('switch')[1]      # only guards depend on the span
+    build(tape)        # compiles the ROW kernels as well

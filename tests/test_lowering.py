@@ -128,7 +128,22 @@ def test_skip_regions_preserve_values(chess_bytes):
     assert t2.info['skip_ops'] >= 2
     _, w64 = OScene(data).render_rows(100, 5, 0, 5)
     assert same_f64(tape_eval.render_rows_waves(t2, 100, 0, 5), w64)
+    assert same_f64(tape_eval.render_rows_waves(t2, 100, 0, 5, tile=64), w64)     # spans cover whole wavefronts
     assert same_f64(tape_eval.render_rows(t2, 100, 0, 5), w64)
+
+
+def test_guards_bounded_over_a_tile_preserve_values(chess_bytes):
+    """The guards may be evaluated for any span [XMIN, XMAX] of a row (the specialised kernels use 256-pixel tiles):
+    a bound that holds over the row's part skips more, and must never skip a region some pixel of the span needs."""
+    s = M.Scene(chess_bytes)
+    s.rescale(2, 2)                     # 2048 wide: 8 tiles of 256
+    tape = s.lower()
+    o = OScene(s.encode())
+    for y0 in (700, 1100, 1408):
+        _, want64 = o.render_rows(2048, 2048, y0, y0 + 1)
+        assert same_f64(tape_eval.render_rows_waves(tape, 2048, y0, y0 + 1, tile=256), want64), y0
+    _, want64 = o.render_rows(2048, 2048, 1408, 1409)
+    assert same_f64(tape_eval.render_rows_waves(tape, 2048, 1408, 1409, tile=64), want64)      # any span of whole wavefronts
 
 
 def test_unfused_chess_tape_equals_oracle(chess_bytes):
