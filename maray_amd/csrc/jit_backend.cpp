@@ -117,6 +117,7 @@ struct Emitter {
     // order the code reads them (one entry per use, shared inside a basic block): the compiler then fetches a block's
     // constants with a few s_load_dwordx4/x8/x16 instead of two s_mov_b32 per use, and the scalar unit -- which also
     // does all the boolean algebra and every region's branch -- is what bounds this kernel.
+    bool assume_guards_zero = false;             // PIXEL: emit the variant for a tile none of whose guard bits is set
     bool out_guard_bits = false;                 // ROW-section OUT of a guard (index >= guard_first): OR its bit into `gacc`
     bool ktab = false;
     std::vector<double> ktab_vals;
@@ -162,6 +163,8 @@ struct Emitter {
         // the double form of a value, materialising it once if needed
         auto dbl = [&](Val *v, const char *hint, uint32_t i, int which) -> std::string {
             if (!v->d.empty()) return v->d;
+            if (v->b == "MR_NONE") return v->d = v->kind == BOOL ? "0.0" : "(-0.0)";
+            if (v->b == "MR_ALL") return v->d = v->kind == BOOL ? "1.0" : "(-1.0)";
             snprintf(name, sizeof name, "%s%u_%c", hint, i, which ? 'b' : 'a');
             out += "    const double ";
             out += name;
@@ -172,11 +175,12 @@ struct Emitter {
 
         struct Open { uint32_t end; bool as_bool; bool nz; };
         std::vector<Open> open;     // SKIPZ / SKIPNZ regions being emitted, innermost last
+        std::vector<uint8_t> forced(n, 0);      // op is the end of a region known to be skipped: its value is the constant 0
         for (uint32_t i = 0; i < n; i++) {
             const uint64_t ins = ops[i];
             const uint32_t op = MARAY_INS_OP(ins), aux = MARAY_INS_AUX(ins), dst = MARAY_INS_DST(ins);
             if (op == MARAY_OP_NOP) continue;
-            Val *va = (op != MARAY_OP_TEXDIM) ? ref(MARAY_INS_A(ins), 0) : nullptr;
+            Val *va = (op != MARAY_OP_TEXDIM && !forced[i]) ? ref(MARAY_INS_A(ins), 0) : nullptr;
             if (op == MARAY_OP_SKIPZ || op == MARAY_OP_SKIPNZ) {
                 // if (some lane still needs it) { region } else result = 0 / 1;  -- a scalar branch on the ballot
                 const bool nz = op == MARAY_OP_SKIPNZ;
@@ -189,6 +193,11 @@ struct Emitter {
                 // region (a boolean guards a boolean AND / OR), the dry run for a row-level one (its guard is a y value)
                 const bool as_bool = row_guard ? (end < bool_hint.size() && bool_hint[end]) : va->kind == BOOL;
                 std::string cond;
+                if (row_guard && !nz && guard_words && MARAY_REF_INDEX(gref) >= guard_first && assume_guards_zero) {
+                    forced[end] = 1;            // nothing of the region is emitted; op `end` becomes the constant
+                    i = end - 1;
+                    continue;
+                }
                 if (row_guard && !nz && guard_words && MARAY_REF_INDEX(gref) >= guard_first) {
                     // a row bound: one bit of a guard word that sits in an SGPR since the kernel's prologue
                     const uint32_t k = MARAY_REF_INDEX(gref) - guard_first;
@@ -223,13 +232,31 @@ struct Emitter {
                                  : "    yout[" + std::to_string(aux) + "] = " + a + ";\n";
                 continue;
             }
-            Val *vb = (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) ? ref(MARAY_INS_B(ins), 1) : nullptr;
+            Val *vb = (op >= MARAY_OP_ADD && op <= MARAY_OP_APP && !forced[i]) ? ref(MARAY_INS_B(ins), 1) : nullptr;
             snprintf(name, sizeof name, "%s%u", prefix, i);
             const std::string self = name;
             Val r;
             std::string e;      // double expression
             std::string be;     // bool expression
             const bool both_bool = va && vb && va->kind == BOOL && vb->kind == BOOL;
+            auto m_and = [](const std::string &a, const std::string &b) -> std::string {
+                if (a == "MR_NONE" || b == "MR_NONE") return "MR_NONE";
+                if (a == "MR_ALL") return b;
+                if (b == "MR_ALL") return a;
+                return "(" + a + " & " + b + ")";
+            };
+            auto m_or = [](const std::string &a, const std::string &b) -> std::string {
+                if (a == "MR_ALL" || b == "MR_ALL") return "MR_ALL";
+                if (a == "MR_NONE") return b;
+                if (b == "MR_NONE") return a;
+                return "(" + a + " | " + b + ")";
+            };
+            auto m_not = [](const std::string &a) -> std::string {
+                return a == "MR_NONE" ? "MR_ALL" : (a == "MR_ALL" ? "MR_NONE" : "~" + a);
+            };
+            if (forced[i]) {
+                if (i < bool_hint.size() && bool_hint[i]) be = "MR_NONE"; else e = "0.0";
+            } else
             switch (op) {
             case MARAY_OP_MOV: r = *va; break;
             case MARAY_OP_NEG:
@@ -243,20 +270,20 @@ struct Emitter {
                 break;
             case MARAY_OP_ADD:
                 // 1.0 + (-(b)) = NOT b
-                if (va->kind == BOOL && va->b == "MR_ALL" && vb->kind == NEGBOOL) be = "~" + vb->b;
-                else if (vb->kind == BOOL && vb->b == "MR_ALL" && va->kind == NEGBOOL) be = "~" + va->b;
+                if (va->kind == BOOL && va->b == "MR_ALL" && vb->kind == NEGBOOL) be = m_not(vb->b);
+                else if (vb->kind == BOOL && vb->b == "MR_ALL" && va->kind == NEGBOOL) be = m_not(va->b);
                 else e = dbl(va, "m", i, 0) + " + " + dbl(vb, "m", i, 1);
                 break;
             case MARAY_OP_MUL:
-                if (both_bool) be = "(" + va->b + " & " + vb->b + ")";
+                if (both_bool) be = m_and(va->b, vb->b);
                 else e = dbl(va, "m", i, 0) + " * " + dbl(vb, "m", i, 1);
                 break;
             case MARAY_OP_MIN:
-                if (both_bool) be = "(" + va->b + " & " + vb->b + ")";
+                if (both_bool) be = m_and(va->b, vb->b);
                 else e = "mr_min(" + dbl(va, "m", i, 0) + ", " + dbl(vb, "m", i, 1) + ")";
                 break;
             case MARAY_OP_MAX:
-                if (both_bool) be = "(" + va->b + " | " + vb->b + ")";
+                if (both_bool) be = m_or(va->b, vb->b);
                 else e = "mr_max(" + dbl(va, "m", i, 0) + ", " + dbl(vb, "m", i, 1) + ")";
                 break;
             case MARAY_OP_ABS: e = "mr_abs(" + dbl(va, "m", i, 0) + ")"; break;
@@ -295,6 +322,10 @@ struct Emitter {
                     out += o.as_bool ? "    } else b" + self + (o2.nz ? " = MR_ALL;\n" : " = MR_NONE;\n")
                                      : "    } else " + self + (o2.nz ? " = 1.0;\n" : " = 0.0;\n");
                 }
+            } else if (be == "MR_NONE" || be == "MR_ALL") {
+                r.kind = BOOL; r.b = be;             // a literal: later ops fold it
+            } else if (!be.empty() && be[0] != '(' && be[0] != '~' && be.compare(0, 3, "mr_") != 0) {
+                r.kind = BOOL; r.b = be;             // folded to one of its operands: an alias, no new variable
             } else if (!be.empty()) {
                 out += "    const mr_mask b" + self + " = " + be + ";\n";
                 r.kind = BOOL; r.b = "b" + self;
@@ -316,8 +347,7 @@ struct Emitter {
 // work-item per row is all the parallelism a straight-line ROW kernel has (4096 rows = 64 waves,
 // each walking thousands of dependent f64 ops: ~45 us for chess, an eighth of the frame).  The y
 // values are independent outputs, so the tape is cut by outputs: chunk k keeps the ops its outputs
-// depend on (ops two chunks share are computed in both) and the rest become NOPs.  SKIP ops are
-// dropped -- legal for any evaluator, and 64 different rows rarely agree anyway.
+// depend on (ops two chunks share are computed in both) and the rest become NOPs.
 struct RowTapeDeps {
     std::vector<std::array<int32_t, 2>> deps;   // per op: the ops that produce its operands (-1: none)
     std::vector<uint32_t> outs;                 // OUT ops, tape order
@@ -339,8 +369,9 @@ RowTapeDeps row_tape_deps(const maray_program &P)
     for (uint32_t j = 0; j < n; j++) {
         const uint64_t ins = P.row_ops[j];
         const uint32_t op = MARAY_INS_OP(ins);
-        if (op == MARAY_OP_NOP || op == MARAY_OP_SKIPZ || op == MARAY_OP_SKIPNZ) continue;
+        if (op == MARAY_OP_NOP) continue;
         if (op != MARAY_OP_TEXDIM) d.deps[j][0] = producer(MARAY_INS_A(ins));
+        if (op == MARAY_OP_SKIPZ || op == MARAY_OP_SKIPNZ) continue;        // reads its guard, leaves ACC and the slots alone
         if (op == MARAY_OP_OUT) { d.outs.push_back(j); continue; }
         if (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) d.deps[j][1] = producer(MARAY_INS_B(ins));
         acc = (int32_t)j;
@@ -349,19 +380,27 @@ RowTapeDeps row_tape_deps(const maray_program &P)
     return d;
 }
 
-// The ROW tape with everything but the cone of the given OUT ops turned into NOPs.
+// The ROW tape with everything but the cone of the given OUT ops turned into NOPs.  A SKIP op stays
+// when the op that ends its region does (and then its guard is needed too): what a region holds
+// feeds nothing outside it, so any part of it can still be skipped as a whole.
 std::vector<uint64_t> row_tape_cone(const maray_program &P, const RowTapeDeps &d, const std::vector<uint32_t> &outs, size_t *cost)
 {
-    std::vector<uint64_t> tape(P.n_row_ops, 0);           // 0 = NOP
-    std::vector<int32_t> st(outs.begin(), outs.end());
+    const uint32_t n = P.n_row_ops;
+    std::vector<uint8_t> need(n, 0);
+    for (uint32_t o : outs) need[o] = 1;
     size_t c = 0;
-    while (!st.empty()) {
-        const int32_t v = st.back(); st.pop_back();
-        if (v < 0 || tape[v]) continue;
-        tape[v] = P.row_ops[v];
+    for (uint32_t j = n; j-- > 0;) {             // producers precede consumers; a region's end follows its SKIP op
+        const uint32_t op = MARAY_INS_OP(P.row_ops[j]);
+        if (op == MARAY_OP_SKIPZ || op == MARAY_OP_SKIPNZ) {
+            const uint32_t end = j + MARAY_INS_AUX(P.row_ops[j]);
+            if (end < n && need[end]) need[j] = 1;
+        }
+        if (!need[j]) continue;
         c++;
-        st.push_back(d.deps[v][0]); st.push_back(d.deps[v][1]);
+        for (int32_t p : d.deps[j]) if (p >= 0) need[p] = 1;
     }
+    std::vector<uint64_t> tape(n, 0);           // 0 = NOP
+    for (uint32_t j = 0; j < n; j++) if (need[j]) tape[j] = P.row_ops[j];
     if (cost) *cost = c;
     return tape;
 }
@@ -401,13 +440,14 @@ uint32_t jit_guard_words(const maray_program &P)
     return (jit_row_guards_enabled() && nw <= 12) ? nw : 0;
 }
 
-// Source of the ROW kernels.
-//  maray_jit_rows: one work-item per row, one wavefront per block, blockIdx.y = chunk of the ROW
-//    section; writes the y values the pixel kernel reads as operands (and, for a program that may
-//    defer tiles to the interpreter, the guards too, bounded over the whole row as it expects).
-//  maray_jit_guards: the guard outputs, evaluated once per 256-pixel tile of every row with
+// Source of the ROW kernel, maray_jit_rows: one wavefront per block, blockIdx.y picks the job.
+//  y < n_chunks: chunk y of the ROW section, one work-item per row; writes the y values the pixel
+//    kernel reads as operands (and, for a program that may defer tiles to the interpreter, the
+//    guards too, bounded over the whole row as the interpreter expects).
+//  y >= n_chunks: guard word y - n_chunks, one work-item per (row, 256-pixel tile), evaluated with
 //    XMIN / XMAX = the tile's ends (a bound over 256 pixels skips far more than one over the
-//    row), one work-item per (row, tile), blockIdx.y = guard word; writes 64 guards as one word.
+//    row); writes 64 guards as one word.
+// One launch for both: the few y-value wavefronts run in the shadow of the guard ones.
 // Plain device_math.h: the rare huge-argument tail of sin is a real (out-of-line) call here.
 std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out)
 {
@@ -423,32 +463,34 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out)
     s += "// generated by libmaray_hip (jit_backend.cpp): ROW section, " + std::to_string(P.n_row_ops) + " ops; y values in " +
          std::to_string(chunks.size()) + " chunks, " + std::to_string(P.n_yvals - n_ynum) + " guards in " + std::to_string(n_gwords) + " words\n";
     s += "#include \"device_math.h\"\n\n";
-    s += "extern \"C\" __global__ void __launch_bounds__(64) maray_jit_rows(double *__restrict__ yvals, const MarayTex *__restrict__ tex,\n"
-         "                                                                 unsigned y0, unsigned rows, unsigned n_yvals, unsigned w)\n{\n"
-         "    const unsigned r = blockIdx.x * 64u + threadIdx.x;\n"
-         "    if (r >= rows) return;\n"
+    s += "extern \"C\" __global__ void __launch_bounds__(64) maray_jit_rows(double *__restrict__ yvals, unsigned long long *__restrict__ gbits,\n"
+         "                                                                 const MarayTex *__restrict__ tex,\n"
+         "                                                                 unsigned y0, unsigned rows, unsigned n_yvals, unsigned w, unsigned n_tx)\n{\n"
+         "    const unsigned long long item = (unsigned long long)blockIdx.x * 64u + threadIdx.x;\n"
+         "    (void)tex; (void)gbits; (void)n_tx;\n"
+         "    if (blockIdx.y < " + std::to_string(chunks.size()) + "u) {\n"
+         "    if (item >= rows) return;\n"
+         "    const unsigned r = (unsigned)item;\n"
          "    const double Y = (double)(y0 + r), XMIN = 0.0, XMAX = (double)(w - 1u);\n"
          "    double *yout = yvals + (size_t)r * n_yvals;\n"
-         "    (void)Y; (void)XMIN; (void)XMAX; (void)tex; (void)yout;\n"
+         "    (void)Y; (void)XMIN; (void)XMAX; (void)yout;\n"
          "    switch (blockIdx.y) {\n";
     for (size_t k = 0; k < chunks.size(); k++) {
         s += "    case " + std::to_string(k) + ": {\n";
         E.section(chunks[k].data(), P.n_row_ops, P.n_row_slots, false, "r");
         s += "    } break;\n";
     }
-    s += "    }\n}\n\n";
+    s += "    }\n    return;\n    }\n";
     if (n_gwords) {
-        s += "extern \"C\" __global__ void __launch_bounds__(64) maray_jit_guards(unsigned long long *__restrict__ gbits, const MarayTex *__restrict__ tex,\n"
-             "                                                                   unsigned y0, unsigned rows, unsigned w, unsigned n_tx)\n{\n"
-             "    const unsigned long long item = (unsigned long long)blockIdx.x * 64u + threadIdx.x;      // (row, tile), tiles of a row adjacent\n"
+        s += "    // guards: (row, tile), the tiles of a row adjacent\n"
              "    if (item >= (unsigned long long)rows * n_tx) return;\n"
              "    const unsigned r = (unsigned)(item / n_tx), tile = (unsigned)(item % n_tx);\n"
              "    const unsigned xlo = tile * 256u, xhi = xlo + 255u < w - 1u ? xlo + 255u : w - 1u;\n"
              "    const double Y = (double)(y0 + r), XMIN = (double)xlo, XMAX = (double)xhi;\n"
              "    unsigned long long gacc = 0ull;\n"
              "    double *yout = nullptr;\n"
-             "    (void)Y; (void)XMIN; (void)XMAX; (void)tex; (void)yout;\n"
-             "    switch (blockIdx.y) {\n";
+             "    (void)Y; (void)XMIN; (void)XMAX; (void)yout;\n"
+             "    switch (blockIdx.y - " + std::to_string(chunks.size()) + "u) {\n";
         E.out_guard_bits = true;
         E.guard_first = n_ynum;
         for (uint32_t j = 0; j < n_gwords; j++) {
@@ -463,8 +505,9 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out)
             s += "    } break;\n";
         }
         s += "    }\n"
-             "    gbits[item * " + std::to_string(n_gwords) + "u + blockIdx.y] = gacc;\n}\n";
+             "    gbits[item * " + std::to_string(n_gwords) + "u + (blockIdx.y - " + std::to_string(chunks.size()) + "u)] = gacc;\n";
     }
+    s += "}\n";
     return s;
 }
 
@@ -498,6 +541,7 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
     if (n_gwords) { E.guard_first = n_ynum; E.guard_words = n_gwords; }
     if (y_lds) E.yv_name = "mr_ylds";
     if (y_lds) s += "__shared__ double mr_ylds[" + std::to_string(n_ynum) + "];\n";
+    if (E.guard_words) s += "__shared__ unsigned long long mr_gq[" + std::to_string(16 * E.guard_words) + "];     // <= 16 tiles per block\n";
     const bool defer = may_defer_tiles(P);
     s += "__shared__ unsigned mr_slow_tile;\n"
          "__device__ inline double mr_defer_sin(double) { mr_slow_tile = 1u; return 0.0; }\n"
@@ -522,10 +566,18 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
         const std::string i = std::to_string(k * 256) + "u + threadIdx.x";
         s += "    const double ys" + std::to_string(k) + " = " + i + " < " + std::to_string(n_ynum) + "u ? yrow[" + i + "] : 0.0;\n";
     }
+    // the guard words of all the block's tiles, fetched here with everything else: a scalar load per trip of the tile
+    // loop would put a full memory latency (the words were just written by maray_jit_guards) on every tile
+    if (E.guard_words) {
+        const std::string nw = std::to_string(E.guard_words);
+        s += "    const unsigned tile0 = blockIdx.x * tiles, my_tiles = n_tx - tile0 < tiles ? n_tx - tile0 : tiles;\n"
+             "    const unsigned long long gs = threadIdx.x < my_tiles * " + nw + "u ? gbits[((size_t)r * n_tx + tile0) * " + nw + "u + threadIdx.x] : 0ull;\n";
+    }
     for (uint32_t k = 0; k < y_rounds; k++) {
         const std::string i = std::to_string(k * 256) + "u + threadIdx.x";
         s += "    if (" + i + " < " + std::to_string(n_ynum) + "u) mr_ylds[" + i + "] = ys" + std::to_string(k) + ";\n";
     }
+    if (E.guard_words) s += "    if (threadIdx.x < " + std::to_string(16 * E.guard_words) + "u) mr_gq[threadIdx.x] = gs;\n";
     s += "    __syncthreads();\n"
          "    const double Y = (double)(y0 + r);\n"
          "    mr_kptr yv = (mr_kptr)yrow;\n"
@@ -536,9 +588,8 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
          "    if (x0 >= w) break;\n"
          "/*MR_KBASE*/";
     if (E.guard_words) {
-        s += "    const __attribute__((address_space(4))) unsigned long long *gk = (const __attribute__((address_space(4))) unsigned long long *)\n"
-             "        (gbits + ((size_t)r * n_tx + (blockIdx.x * tiles + t)) * " + std::to_string(E.guard_words) + "u);\n";
-        for (uint32_t j = 0; j < E.guard_words; j++) s += "    const mr_mask gq" + std::to_string(j) + " = gk[" + std::to_string(j) + "];\n";
+        for (uint32_t j = 0; j < E.guard_words; j++)
+            s += "    const mr_mask gq" + std::to_string(j) + " = mr_uniform64(mr_gq[t * " + std::to_string(E.guard_words) + "u + " + std::to_string(j) + "u]);\n";
     }
     s += "    const unsigned x = x0 + threadIdx.x;\n"
          "    const double X = (double)x;\n"
@@ -556,7 +607,21 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
         const char *e_ = getenv("MARAY_JIT_KTAB");
         E.ktab = !(e_ && e_[0] == '0');
     }
-    E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+    if (E.guard_words) {
+        // Two variants of the section: one for a tile with no guard bit set (every row-guarded region is the constant 0
+        // there and the compiler folds what depends on it: for chess.maray all that is left is the background), one
+        // for the general case.  One scalar test per tile picks; most tiles of a sparse scene take the short one.
+        std::string any = "gq0";
+        for (uint32_t j = 1; j < E.guard_words; j++) any += " | gq" + std::to_string(j);
+        s += "    if ((" + any + ") == 0ull) {\n";
+        E.assume_guards_zero = true;
+        E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+        E.assume_guards_zero = false;
+        s += "    } else {\n";
+        E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+        s += "    }\n";
+    } else
+        E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
     {
         std::string tab;
         if (!E.ktab_vals.empty()) {
@@ -574,8 +639,14 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
                   "    const mr_kptr mr_kc = (mr_kptr)mr_kbase;\n");
     }
     if (defer) s += "    if (mr_defer != 0.0f && x < w) mr_slow_tile = 1u;\n";
-    s += "    if (x < w) {\n"
-         "        const size_t p = ((size_t)r * w + x) * 3;\n"
+    if (const char *ex = getenv("MARAY_JIT_EXP")) {       // EXPERIMENT ONLY
+        if (!strcmp(ex, "nostore")) s += "    asm volatile(\"\" :: \"v\"(o0), \"v\"(o1), \"v\"(o2));\n    if (0) {\n";
+        else if (!strcmp(ex, "store1")) s += "    if (x < w && rgb8) rgb8[((size_t)r * w + x) * 3] = (unsigned char)mr_cast_u8(o0 + o1 + o2);\n    if (0) {\n";
+        else if (!strcmp(ex, "nocast")) s += "    if (x < w && rgb8) { const size_t p = ((size_t)r * w + x) * 3; rgb8[p] = (unsigned char)(int)o0; rgb8[p+1] = (unsigned char)(int)o1; rgb8[p+2] = (unsigned char)(int)o2; }\n    if (0) {\n";
+        else s += "    if (x < w) {\n";
+    } else
+    s += "    if (x < w) {\n";
+    s += "        const size_t p = ((size_t)r * w + x) * 3;\n"
          "        if (rgb64) { rgb64[p] = o0; rgb64[p + 1] = o1; rgb64[p + 2] = o2; }\n"
          "        if (rgb8) {\n"
          "            rgb8[p] = (unsigned char)mr_cast_u8(o0);\n"
@@ -646,7 +717,6 @@ struct JitBackend final : Backend {
     double *d_rgb64 = nullptr; size_t rgb64_cap = 0;
     hipStream_t own_stream = nullptr;
     uint32_t n_row_chunks = 1, n_gwords = 0;
-    hipFunction_t f_guards = nullptr;
     unsigned long long *d_gbits = nullptr; size_t gbits_cap = 0;
     bool has_sin = false;               // some Sin argument is not proven bounded: tiles may be deferred to `slow`
 
@@ -694,7 +764,7 @@ struct JitBackend final : Backend {
             HIP_TRY(hipModuleLoadData(&mod_rows, code_rows.data()));
             HIP_TRY(hipModuleGetFunction(&f_rows, mod_rows, "maray_jit_rows"));
             n_gwords = jit_guard_words(prog);
-            if (n_gwords) HIP_TRY(hipModuleGetFunction(&f_guards, mod_rows, "maray_jit_guards"));
+
         }
         HIP_TRY(hipStreamCreate(&own_stream));
         std::vector<DevTex> descs(n_tex ? n_tex : 1);
@@ -727,22 +797,18 @@ struct JitBackend final : Backend {
         unsigned n_yvals = P.n_yvals;
         if (rows_pass && P.n_row_ops) {
             unsigned yy0 = y0, rr = rows_total, ww = w;
-            void *args[] = {&d_yvals, &d_tex, &yy0, &rr, &n_yvals, &ww};
-            HIP_TRY(hipModuleLaunchKernel(f_rows, (rows_total + 63) / 64, n_row_chunks, 1, 64, 1, 1, 0, st, args, nullptr));
-            if (n_gwords) {         // the guards of every (row, 256-pixel tile)
-                unsigned n_tx_ = (w + 255) / 256;
-                const uint64_t items = (uint64_t)rows_total * n_tx_;
-                if ((items + 63) / 64 > 0x7FFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
-                void *gargs[] = {&d_gbits, &d_tex, &yy0, &rr, &ww, &n_tx_};
-                HIP_TRY(hipModuleLaunchKernel(f_guards, (unsigned)((items + 63) / 64), n_gwords, 1, 64, 1, 1, 0, st, gargs, nullptr));
-            }
+            unsigned n_tx_ = (w + 255) / 256;
+            const uint64_t items = n_gwords ? (uint64_t)rows_total * n_tx_ : rows_total;     // guards: one per (row, 256-pixel tile)
+            if ((items + 63) / 64 > 0x7FFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
+            void *args[] = {&d_yvals, &d_gbits, &d_tex, &yy0, &rr, &n_yvals, &ww, &n_tx_};
+            HIP_TRY(hipModuleLaunchKernel(f_rows, (unsigned)((items + 63) / 64), n_row_chunks + n_gwords, 1, 64, 1, 1, 0, st, args, nullptr));
         }
         const unsigned n_tx = (w + 255) / 256;
         const uint64_t n_tiles = (uint64_t)n_tx * rows_total;
         // tiles per block: amortise the per-block prologue while leaving >= 16 blocks per CU to balance the tail
         // (chess @4096^2, tiles = 1 / 2 / 4 / 8 / 16: 0.385 / 0.366 / 0.353 / 0.354 / 0.340 ms)
         unsigned tiles = has_sin ? 1u : (unsigned)std::min<uint64_t>(std::min<uint64_t>(16, n_tx), std::max<uint64_t>(1, n_tiles / 4096));
-        if (const char *e_ = getenv("MARAY_JIT_TILES")) if (!has_sin && atoi(e_) > 0) tiles = (unsigned)atoi(e_);      // tuning knob
+        if (const char *e_ = getenv("MARAY_JIT_TILES")) if (!has_sin && atoi(e_) > 0) tiles = (unsigned)std::min(16, atoi(e_));      // tuning knob (the kernel stages guard words for <= 16 tiles)
         const unsigned gx = (n_tx + tiles - 1) / tiles;
         if (n_tiles > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
         ensure(d_flags, flags_cap, (size_t)n_tiles + 1);                    // work list {count, tile, ...} of deferred tiles

@@ -43,9 +43,9 @@ def test_chess_uses_the_pure_bounded_step_sin(chess_bytes):
 
 
 def test_row_section_is_cut_into_chunks(chess_bytes):
-    """maray_jit_rows evaluates independent chunks of the ROW section side by side (blockIdx.y): every y value the
-    pixel kernel reads as an operand is written by exactly one chunk.  The guards are not y values here: maray_jit_guards
-    evaluates them per 256-pixel tile (XMIN / XMAX = the tile's ends) and packs them 64 to a word.  Both kernels build."""
+    """maray_jit_rows evaluates independent jobs side by side (blockIdx.y).  The first k are chunks of the ROW section:
+    every y value the pixel kernel reads as an operand is written by exactly one of them.  The rest are guard words:
+    the guards are evaluated per 256-pixel tile (XMIN / XMAX = the tile's ends) and packed 64 to a word.  It builds."""
     import re
     s = M.Scene(chess_bytes)
     s.rescale(4, 4)
@@ -56,7 +56,7 @@ def test_row_section_is_cut_into_chunks(chess_bytes):
     assert L.maray_jit_source_rows(C.byref(tape.program), C.byref(src), C.byref(k)) == 0, L.maray_last_error()
     text = C.string_at(src).decode()
     L.maray_free(src)
-    rows_src, guards_src = text.split('maray_jit_guards')
+    rows_src, guards_src = text.split('// guards: (row, tile)')
     assert 2 <= k.value <= 16 and rows_src.count('    case ') == k.value
     written = sorted(int(m) for m in re.findall(r'yout\[(\d+)\] = ', rows_src))
     n_num = len(written)
@@ -65,4 +65,4 @@ def test_row_section_is_cut_into_chunks(chess_bytes):
     assert len(re.findall(r'gacc \|= ', guards_src)) == n_guards and 'yout[' not in guards_src.split('switch')[1]
     assert guards_src.count('    case ') == (n_guards + 63) // 64
     assert 'XMIN' in guards_src and 'XMIN' not in rows_src.split('switch')[1]      # only guards depend on the span
-    build(tape)        # compiles the ROW kernels as well
+    build(tape)        # compiles the ROW kernel as well
