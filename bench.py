@@ -63,12 +63,13 @@ def main():
     # N = 1: config 3, chess.maray regenerated at 4096 x 4096 (exact power-of-two rescale).  N > 1: the same scene
     # at N x 4096^2 pixels (8192x4096, 8192^2, 16384x8192 = config 4's width), rows dealt to the ranks in interleaved
     # 256-row blocks so that every rank sees sky and board alike: equal pixels per rank, no data-path collective.
-    from maray_amd.sharding import interleaved_blocks, max_over_ranks, scene_scale
+    from maray_amd.sharding import interleaved_blocks, interleaved_layout, max_over_ranks, scene_scale
     sx, sy = scene_scale(n_gpus)
     scene.rescale(sx, sy)
     w_img, h_total = scene.size
     tape = scene.lower(row_guards=os.environ.get('MARAY_BENCH_ROW_GUARDS', '1') != '0')
     blocks = interleaved_blocks(rank, n_gpus, h_total, 256)
+    layout = interleaved_layout(rank, n_gpus, h_total, 256)     # the same rows as one launch (None: ragged, block by block)
     rows_mine = sum(b - a for a, b in blocks)
 
     backends = {'tape': M.BACKEND_TAPE, 'tape-smem': M.BACKEND_TAPE_SMEM, 'jit': M.BACKEND_JIT}
@@ -91,6 +92,9 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
+        if layout is not None:
+            ctx.render_blocks_device(w_img, h_total, *layout, d_rgb8=out8.data_ptr(), stream=stream)
+            return
         off = 0
         for a, b in blocks:
             ctx.render_rows_device(w_img, h_total, a, b, d_rgb8=out8.data_ptr() + off * w_img * 3, stream=stream)

@@ -155,6 +155,12 @@ int maray_hip_render_rows(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uin
  * (a hipStream_t, NULL = the null stream); returns without synchronising. */
 int maray_hip_render_rows_device(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
                                  void *d_rgb8, void *d_rgb64, void *stream);
+/* Several row ranges in one launch: n_blocks blocks of block_rows consecutive rows, the first at y0, block_stride
+ * rows apart (block_stride >= block_rows); outputs packed block after block.  This is how one rank of a multi-GPU
+ * render takes its interleaved share of an image (blocks dealt round-robin, src/render.rs:35-99 deals rows the same
+ * way to Rayon workers) without paying a launch per block. */
+int maray_hip_render_blocks_device(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uint32_t block_rows, uint32_t block_stride,
+                                   uint32_t n_blocks, void *d_rgb8, void *d_rgb64, void *stream);
 /* Time `reps` launches of the pixel kernel for rows [y0,y1) with HIP events on
  * the launch stream; returns the average milliseconds per launch. */
 int maray_hip_time_rows(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,

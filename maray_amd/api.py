@@ -99,6 +99,7 @@ def lib():
         'maray_hip_ctx_free': (None, [vp]),
         'maray_hip_render_rows': (C.c_int, [vp, u32, u32, u32, u32, vp, vp]),
         'maray_hip_render_rows_device': (C.c_int, [vp, u32, u32, u32, u32, vp, vp, vp]),
+        'maray_hip_render_blocks_device': (C.c_int, [vp, u32, u32, u32, u32, u32, u32, vp, vp, vp]),
         'maray_hip_time_rows': (C.c_int, [vp, u32, u32, u32, u32, vp, vp, C.c_int, C.POINTER(C.c_float)]),
         'maray_hip_kernel_name': (C.c_char_p, [vp]),
         'maray_gen_to_image': (C.c_int, [vp, C.POINTER(Texture), u32, C.POINTER(GenOpts), Report, REPORT_FN, vp, vp,
@@ -271,6 +272,11 @@ class Context:
 
     def render_rows_device(self, w, h, y0, y1, d_rgb8=0, d_rgb64=0, stream=0):
         _check(lib().maray_hip_render_rows_device(self._h, w, h, y0, y1, d_rgb8 or None, d_rgb64 or None, stream or None))
+
+    def render_blocks_device(self, w, h, y0, block_rows, block_stride, n_blocks, d_rgb8=0, d_rgb64=0, stream=0):
+        """n_blocks blocks of block_rows rows, block_stride apart, first at y0, in ONE launch; outputs packed."""
+        _check(lib().maray_hip_render_blocks_device(self._h, w, h, y0, block_rows, block_stride, n_blocks,
+                                                    d_rgb8 or None, d_rgb64 or None, stream or None))
 
     def time_rows(self, w, h, y0, y1, d_rgb8=0, d_rgb64=0, reps=5):
         ms = C.c_float()

@@ -350,7 +350,21 @@ int maray_hip_render_rows_device(maray_ctx *c, uint32_t w, uint32_t h, uint32_t 
         REQUIRE(c && c->backend, "null context");
         check_rows(w, h, y0, y1);
         if (y0 == y1 || w == 0) return;
-        c->backend->render_device(w, h, y0, y1, d_rgb8, d_rgb64, stream);
+        c->backend->render_device(w, h, RowBlocks::range(y0, y1), d_rgb8, d_rgb64, stream);
+    });
+}
+
+int maray_hip_render_blocks_device(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uint32_t block_rows, uint32_t block_stride,
+                                   uint32_t n_blocks, void *d_rgb8, void *d_rgb64, void *stream)
+{
+    return guard([&] {
+        REQUIRE(c && c->backend, "null context");
+        if (n_blocks == 0 || block_rows == 0 || w == 0) return;
+        REQUIRE(n_blocks == 1 || block_stride >= block_rows, "row blocks overlap: block_stride < block_rows");
+        const uint64_t last = (uint64_t)y0 + (uint64_t)(n_blocks - 1) * block_stride + block_rows;       // one past the last row
+        REQUIRE(last <= 0xFFFFFFFFull && (uint64_t)n_blocks * block_rows <= 0xFFFFFFFFull, "row blocks out of range");
+        check_rows(w, h, y0, (uint32_t)last);
+        c->backend->render_device(w, h, RowBlocks{y0, n_blocks * block_rows, block_rows, n_blocks == 1 ? 0u : block_stride}, d_rgb8, d_rgb64, stream);
     });
 }
 

@@ -10,10 +10,18 @@
 
 namespace maray {
 
+// The image rows of one launch: n_rows rows in blocks of block_rows consecutive ones, block_stride apart.
+// Launch row r is image row y0 + (r / block_rows) * block_stride + r % block_rows; outputs are packed in
+// launch-row order.  A contiguous range [y0, y1) is one block: {y0, y1 - y0, y1 - y0, 0}.
+struct RowBlocks {
+    uint32_t y0, n_rows, block_rows, block_stride;
+    static RowBlocks range(uint32_t y0, uint32_t y1) { return RowBlocks{y0, y1 - y0, y1 > y0 ? y1 - y0 : 1u, 0u}; }
+};
+
 struct Backend {
     virtual ~Backend() {}
-    // rows [y0,y1) into device buffers, enqueued on `stream`, no synchronisation
-    virtual void render_device(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, void *d8, void *d64, void *stream) = 0;
+    // the rows of `rb` into device buffers, enqueued on `stream`, no synchronisation
+    virtual void render_device(uint32_t w, uint32_t h, const RowBlocks &rb, void *d8, void *d64, void *stream) = 0;
     // rows [y0,y1) into host buffers (blocking)
     virtual void render_host(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint8_t *rgb8, double *rgb64) = 0;
     // average ms per launch of the pixel kernel, HIP events on the launch stream
@@ -22,7 +30,7 @@ struct Backend {
     // Tape interpreter only: re-evaluate the 256-pixel tiles of the device work list
     // {count, tile, tile, ...} (tile = row_in_launch * ceil(w/256) + x/256), reading the row
     // values from `yvals` instead of running the ROW section.  Enqueued on `stream`.
-    virtual void render_flagged(uint32_t, uint32_t, uint32_t, void *, void *, void *, const unsigned *, const double *) {
+    virtual void render_flagged(uint32_t, const RowBlocks &, void *, void *, void *, const unsigned *, const double *) {
         throw Error{MARAY_E_INTERNAL, "render_flagged is not supported by this backend"};
     }
 };
@@ -32,7 +40,7 @@ int hip_device_count();
 Backend *make_tape_backend(int device, const maray_program &prog, const maray_texture *tex, uint32_t n_tex, bool lds_variant);
 Backend *make_jit_backend(int device, const maray_program &prog, const maray_texture *tex, uint32_t n_tex);
 std::string jit_source(const maray_program &prog, int min_waves = 8);   // PIXEL kernel source (__launch_bounds__(256, min_waves)); throws Error
-std::string jit_source_rows(const maray_program &prog, uint32_t *n_chunks_out = nullptr);   // ROW kernel source (blockIdx.y = chunk)
+std::string jit_source_rows(const maray_program &prog, uint32_t *n_chunks_out = nullptr, uint32_t *n_gjobs_out = nullptr);   // ROW kernel source (blockIdx.y = chunk)
 void jit_compile(const std::string &src, std::vector<char> &code, std::string &log);     // hiprtc, gfx950; throws Error
 void validate_program(const maray_program &p);
 

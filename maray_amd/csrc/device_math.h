@@ -59,9 +59,11 @@ MARAY_DEV double mr_ln(double a) { return maray_libm_log(a); }
 // Rust `f64 as u8` (src/render.rs:92-94): saturating, NaN -> 0, truncation.
 MARAY_DEV unsigned mr_cast_u8(double v)
 {
-    if (!(v > 0.0)) return 0u;
-    if (v >= 255.0) return 255u;
-    return (unsigned)v;
+    // v_cvt_u32_f64 truncates toward zero, saturates (negative -> 0, >= 2^32 -> 0xffffffff) and turns NaN into 0:
+    // Rust's `as u32`; the min makes it `as u8`.  Inline asm: the C cast is undefined out of range, the instruction is not.
+    unsigned u;
+    asm("v_cvt_u32_f64 %0, %1" : "=v"(u) : "v"(v));
+    return u < 255u ? u : 255u;
 }
 // Rust `f64 as u32` (src/textures.rs:32-33): saturating, NaN -> 0.
 MARAY_DEV unsigned mr_cast_u32(double v)

@@ -47,6 +47,7 @@ struct KArgs {
     double *rgb64;
     uint32_t n_ops, n_consts, n_yvals, n_slots, n_lds_slots;
     uint32_t w, y0, rows;      // image width, first row, row count of this launch
+    uint32_t blk_rows, blk_stride;   // launch row r is image row y0 + (r / blk_rows) * blk_stride + r % blk_rows (RowBlocks)
     uint32_t tiles_per_row, n_tiles;
 };
 
@@ -171,7 +172,7 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_pixels(const KArgs A)
         const uint32_t tile = A.tile_list ? A.tile_list[1 + wi] : wi;
         const uint32_t r = tile / A.tiles_per_row;                 // row within this launch (uniform)
         const uint32_t x = (tile - r * A.tiles_per_row) * BLOCK + threadIdx.x;
-        const uint32_t y = A.y0 + r;
+        const uint32_t y = A.y0 + (r / A.blk_rows) * A.blk_stride + r % A.blk_rows;
         const double *yrow = A.yvals + (size_t)r * A.n_yvals;
         double o0 = 0.0, o1 = 0.0, o2 = 0.0;
         run_tape<TAPE_LDS, false>(A, tape_lds, consts_lds, slots, spill_base, spill_stride, yrow,
@@ -200,7 +201,7 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_rows(const KArgs A)
     const uint32_t rr = r < A.rows ? r : A.rows - 1;               // keep the wave uniform; surplus lanes recompute the last row
     double o0, o1, o2;
     run_tape<false, true>(A, nullptr, nullptr, slots, spill_base, spill_stride, nullptr,
-                          0.0, (double)(A.y0 + rr), A.yout + (size_t)rr * A.n_yvals, o0, o1, o2);
+                          0.0, (double)(A.y0 + (rr / A.blk_rows) * A.blk_stride + rr % A.blk_rows), A.yout + (size_t)rr * A.n_yvals, o0, o1, o2);
 }
 
 #define HIP_TRY(expr)                                                                              \
@@ -293,10 +294,9 @@ struct TapeBackend final : Backend {
         cap = n;
     }
 
-    void launch(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, unsigned char *d8, double *d64, hipStream_t st, bool rows_pass,
+    void launch(uint32_t w, const RowBlocks &rb, unsigned char *d8, double *d64, hipStream_t st, bool rows_pass,
                 const unsigned *tile_list = nullptr, const double *ext_yvals = nullptr) {
-        (void)h;
-        const uint32_t rows = y1 - y0;
+        const uint32_t rows = rb.n_rows, y0 = rb.y0;
         if (!rows || !w) return;
         if (!ext_yvals) ensure(d_yvals, yvals_cap, (size_t)rows * std::max<uint32_t>(P.n_yvals, 1));
         if (ext_yvals) rows_pass = false;
@@ -305,7 +305,7 @@ struct TapeBackend final : Backend {
             R.tape = d_row_ops; R.consts = d_consts; R.yout = d_yvals; R.tex = d_tex;
             R.n_ops = P.n_row_ops; R.n_consts = P.n_consts; R.n_yvals = P.n_yvals;
             R.n_slots = P.n_row_slots; R.n_lds_slots = row_lds_slots;
-            R.w = w; R.y0 = y0; R.rows = rows;
+            R.w = w; R.y0 = y0; R.rows = rows; R.blk_rows = rb.block_rows; R.blk_stride = rb.block_stride;
             const uint32_t grid = (rows + BLOCK - 1) / BLOCK;
             if (P.n_row_slots > row_lds_slots) {
                 ensure(d_spill, spill_cap, std::max(spill_cap, (size_t)(P.n_row_slots - row_lds_slots) * grid * BLOCK));
@@ -320,7 +320,7 @@ struct TapeBackend final : Backend {
         A.rgb8 = d8; A.rgb64 = d64;
         A.n_ops = P.n_pix_ops; A.n_consts = P.n_consts; A.n_yvals = P.n_yvals;
         A.n_slots = P.n_pix_slots; A.n_lds_slots = n_lds_slots;
-        A.w = w; A.y0 = y0; A.rows = rows;
+        A.w = w; A.y0 = y0; A.rows = rows; A.blk_rows = rb.block_rows; A.blk_stride = rb.block_stride;
         A.tiles_per_row = (w + BLOCK - 1) / BLOCK;
         const uint64_t tiles = (uint64_t)A.tiles_per_row * rows;
         if (tiles > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
@@ -335,15 +335,15 @@ struct TapeBackend final : Backend {
         HIP_TRY(hipGetLastError());
     }
 
-    void render_device(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, void *d8, void *d64, void *stream) override {
+    void render_device(uint32_t w, uint32_t, const RowBlocks &rb, void *d8, void *d64, void *stream) override {
         HIP_TRY(hipSetDevice(device));
-        launch(w, h, y0, y1, (unsigned char *)d8, (double *)d64, (hipStream_t)stream, true);
+        launch(w, rb, (unsigned char *)d8, (double *)d64, (hipStream_t)stream, true);
     }
 
-    void render_flagged(uint32_t w, uint32_t y0, uint32_t y1, void *d8, void *d64, void *stream, const unsigned *flags,
+    void render_flagged(uint32_t w, const RowBlocks &rb, void *d8, void *d64, void *stream, const unsigned *flags,
                         const double *yvals) override {
         HIP_TRY(hipSetDevice(device));
-        launch(w, 0, y0, y1, (unsigned char *)d8, (double *)d64, (hipStream_t)stream, false, flags, yvals);
+        launch(w, rb, (unsigned char *)d8, (double *)d64, (hipStream_t)stream, false, flags, yvals);
     }
 
     void render_host(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint8_t *rgb8, double *rgb64) override {
@@ -351,7 +351,7 @@ struct TapeBackend final : Backend {
         const size_t n = (size_t)(y1 - y0) * w * 3;
         if (rgb8) ensure(d_rgb8, rgb8_cap, n);
         if (rgb64) ensure(d_rgb64, rgb64_cap, n);
-        launch(w, h, y0, y1, rgb8 ? d_rgb8 : nullptr, rgb64 ? d_rgb64 : nullptr, own_stream, true);
+        launch(w, RowBlocks::range(y0, y1), rgb8 ? d_rgb8 : nullptr, rgb64 ? d_rgb64 : nullptr, own_stream, true);
         if (rgb8) HIP_TRY(hipMemcpyAsync(rgb8, d_rgb8, n, hipMemcpyDeviceToHost, own_stream));
         if (rgb64) HIP_TRY(hipMemcpyAsync(rgb64, d_rgb64, n * 8, hipMemcpyDeviceToHost, own_stream));
         HIP_TRY(hipStreamSynchronize(own_stream));
@@ -363,11 +363,11 @@ struct TapeBackend final : Backend {
         unsigned char *p8 = (unsigned char *)d8;
         double *p64 = (double *)d64;
         if (!p8 && !p64) { ensure(d_rgb8, rgb8_cap, n); p8 = d_rgb8; }
-        launch(w, h, y0, y1, p8, p64, own_stream, true);   // warm-up + y values
+        launch(w, RowBlocks::range(y0, y1), p8, p64, own_stream, true);   // warm-up + y values
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, own_stream));
-        for (int i = 0; i < reps; i++) launch(w, h, y0, y1, p8, p64, own_stream, false);   // pixel kernel only
+        for (int i = 0; i < reps; i++) launch(w, RowBlocks::range(y0, y1), p8, p64, own_stream, false);   // pixel kernel only
         HIP_TRY(hipEventRecord(e1, own_stream));
         HIP_TRY(hipEventSynchronize(e1));
         float ms = 0.f;

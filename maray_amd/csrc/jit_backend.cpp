@@ -226,7 +226,7 @@ struct Emitter {
             if (op == MARAY_OP_OUT) {
                 const std::string a = dbl(va, "m", i, 0);
                 if (!pixel && out_guard_bits && aux >= guard_first)
-                    out += "    gacc |= (" + a + " != 0.0) ? (1ull << " + std::to_string((aux - guard_first) % 64) + ") : 0ull;\n";
+                    out += "    gacc |= (" + a + " != 0.0) ? (1ull << " + std::to_string((aux - guard_first) % 16) + ") : 0ull;\n";
                 else
                     out += pixel ? "    o" + std::to_string(aux) + " = " + a + ";\n"
                                  : "    yout[" + std::to_string(aux) + "] = " + a + ";\n";
@@ -444,17 +444,20 @@ uint32_t jit_guard_words(const maray_program &P)
 //  y < n_chunks: chunk y of the ROW section, one work-item per row; writes the y values the pixel
 //    kernel reads as operands (and, for a program that may defer tiles to the interpreter, the
 //    guards too, bounded over the whole row as the interpreter expects).
-//  y >= n_chunks: guard word y - n_chunks, one work-item per (row, 256-pixel tile), evaluated with
-//    XMIN / XMAX = the tile's ends (a bound over 256 pixels skips far more than one over the
-//    row); writes 64 guards as one word.
+//  y >= n_chunks: guards 16 (y - n_chunks) .. +15, one work-item per (row, 256-pixel tile),
+//    evaluated with XMIN / XMAX = the tile's ends (a bound over 256 pixels skips far more than
+//    one over the row); writes its 16 bits of the tile's guard words (64 guards per word).  Small
+//    jobs on purpose: each is one long dependent chain, and only more wavefronts hide that.
 // One launch for both: the few y-value wavefronts run in the shadow of the guard ones.
 // Plain device_math.h: the rare huge-argument tail of sin is a real (out-of-line) call here.
-std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out)
+std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint32_t *n_gjobs_out)
 {
     validate_program(P);
     Emitter E(P);
     const RowTapeDeps deps = row_tape_deps(P);
     const uint32_t n_ynum = numeric_yvals(P), n_gwords = jit_guard_words(P);
+    const uint32_t n_gjobs = n_gwords ? (P.n_yvals - n_ynum + 15) / 16 : 0;       // 16 guards = a quarter of a word per job
+    if (n_gjobs_out) *n_gjobs_out = n_gjobs;
     // the interpreter (which drains deferred tiles from the same y-value table) does read the guard values
     const uint32_t out_limit = may_defer_tiles(P) ? 0xFFFFFFFFu : n_ynum;
     const std::vector<std::vector<uint64_t>> chunks = split_row_tape(P, deps, out_limit);
@@ -465,13 +468,14 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out)
     s += "#include \"device_math.h\"\n\n";
     s += "extern \"C\" __global__ void __launch_bounds__(64) maray_jit_rows(double *__restrict__ yvals, unsigned long long *__restrict__ gbits,\n"
          "                                                                 const MarayTex *__restrict__ tex,\n"
-         "                                                                 unsigned y0, unsigned rows, unsigned n_yvals, unsigned w, unsigned n_tx)\n{\n"
+         "                                                                 unsigned y0, unsigned rows, unsigned n_yvals, unsigned w, unsigned n_tx,\n"
+         "                                                                 unsigned blk_rows, unsigned blk_stride)\n{\n"
          "    const unsigned long long item = (unsigned long long)blockIdx.x * 64u + threadIdx.x;\n"
          "    (void)tex; (void)gbits; (void)n_tx;\n"
          "    if (blockIdx.y < " + std::to_string(chunks.size()) + "u) {\n"
          "    if (item >= rows) return;\n"
          "    const unsigned r = (unsigned)item;\n"
-         "    const double Y = (double)(y0 + r), XMIN = 0.0, XMAX = (double)(w - 1u);\n"
+         "    const double Y = (double)(y0 + (r / blk_rows) * blk_stride + r % blk_rows), XMIN = 0.0, XMAX = (double)(w - 1u);\n"
          "    double *yout = yvals + (size_t)r * n_yvals;\n"
          "    (void)Y; (void)XMIN; (void)XMAX; (void)yout;\n"
          "    switch (blockIdx.y) {\n";
@@ -486,18 +490,18 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out)
              "    if (item >= (unsigned long long)rows * n_tx) return;\n"
              "    const unsigned r = (unsigned)(item / n_tx), tile = (unsigned)(item % n_tx);\n"
              "    const unsigned xlo = tile * 256u, xhi = xlo + 255u < w - 1u ? xlo + 255u : w - 1u;\n"
-             "    const double Y = (double)(y0 + r), XMIN = (double)xlo, XMAX = (double)xhi;\n"
+             "    const double Y = (double)(y0 + (r / blk_rows) * blk_stride + r % blk_rows), XMIN = (double)xlo, XMAX = (double)xhi;\n"
              "    unsigned long long gacc = 0ull;\n"
              "    double *yout = nullptr;\n"
              "    (void)Y; (void)XMIN; (void)XMAX; (void)yout;\n"
              "    switch (blockIdx.y - " + std::to_string(chunks.size()) + "u) {\n";
         E.out_guard_bits = true;
         E.guard_first = n_ynum;
-        for (uint32_t j = 0; j < n_gwords; j++) {
+        for (uint32_t j = 0; j < n_gjobs; j++) {
             std::vector<uint32_t> outs;
             for (uint32_t o : deps.outs) {
                 const uint32_t aux = MARAY_INS_AUX(P.row_ops[o]);
-                if (aux >= n_ynum + 64 * j && aux < n_ynum + 64 * (j + 1)) outs.push_back(o);
+                if (aux >= n_ynum + 16 * j && aux < n_ynum + 16 * (j + 1)) outs.push_back(o);
             }
             const std::vector<uint64_t> tape = row_tape_cone(P, deps, outs, nullptr);
             s += "    case " + std::to_string(j) + ": {\n";
@@ -505,7 +509,7 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out)
             s += "    } break;\n";
         }
         s += "    }\n"
-             "    gbits[item * " + std::to_string(n_gwords) + "u + (blockIdx.y - " + std::to_string(chunks.size()) + "u)] = gacc;\n";
+             "    ((unsigned short *)gbits)[item * " + std::to_string(4 * n_gwords) + "u + (blockIdx.y - " + std::to_string(chunks.size()) + "u)] = (unsigned short)gacc;\n";
     }
     s += "}\n";
     return s;
@@ -556,8 +560,9 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
          "                                                                    const double *__restrict__ yvals, const MarayTex *__restrict__ tex,\n"
          "                                                                    unsigned *__restrict__ tile_list, unsigned tile_base,\n"
          "                                                                    const unsigned long long *__restrict__ gbits, unsigned n_tx,\n"
-         "                                                                    unsigned w, unsigned y0, unsigned n_yvals, unsigned tiles)\n{\n"
-         "    const unsigned r = blockIdx.y;\n"
+         "                                                                    unsigned w, unsigned y0, unsigned n_yvals, unsigned tiles,\n"
+         "                                                                    unsigned blk_rows, unsigned blk_stride, unsigned row_base)\n{\n"
+         "    const unsigned r = blockIdx.y;                     // row of this launch; row_base + r = row of the whole call\n"
          "    const double *yrow = yvals + (size_t)r * n_yvals;\n";
     if (defer) s += "    if (threadIdx.x == 0) mr_slow_tile = 0u;\n";
     // every load of the prologue is issued before the first use: one memory latency, not one per round
@@ -579,11 +584,13 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
     }
     if (E.guard_words) s += "    if (threadIdx.x < " + std::to_string(16 * E.guard_words) + "u) mr_gq[threadIdx.x] = gs;\n";
     s += "    __syncthreads();\n"
-         "    const double Y = (double)(y0 + r);\n"
+         "    const double Y = (double)(y0 + ((row_base + r) / blk_rows) * blk_stride + (row_base + r) % blk_rows);     // -> image row (RowBlocks)\n"
          "    mr_kptr yv = (mr_kptr)yrow;\n"
          "    const __attribute__((address_space(4))) unsigned *yw = (const __attribute__((address_space(4))) unsigned *)yv;\n"
          "    (void)Y; (void)yv; (void)yw; (void)tex; (void)gbits; (void)n_tx;\n";
-    s += "    for (unsigned t = 0; t < tiles; t++) {\n"
+    s += "    const unsigned mr_lane = threadIdx.x & 63u;                              // dword mr_lane of a wave's RGB8 run starts\n"
+         "    const unsigned mr_src = (mr_lane * 4u) / 3u, mr_shift = ((mr_lane * 4u) % 3u) * 8u;   // in pixel mr_src, mr_shift bits in\n"
+         "    for (unsigned t = 0; t < tiles; t++) {\n"
          "    const unsigned x0 = (blockIdx.x * tiles + t) * 256u;\n"
          "    if (x0 >= w) break;\n"
          "/*MR_KBASE*/";
@@ -639,19 +646,22 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
                   "    const mr_kptr mr_kc = (mr_kptr)mr_kbase;\n");
     }
     if (defer) s += "    if (mr_defer != 0.0f && x < w) mr_slow_tile = 1u;\n";
-    if (const char *ex = getenv("MARAY_JIT_EXP")) {       // EXPERIMENT ONLY
-        if (!strcmp(ex, "nostore")) s += "    asm volatile(\"\" :: \"v\"(o0), \"v\"(o1), \"v\"(o2));\n    if (0) {\n";
-        else if (!strcmp(ex, "store1")) s += "    if (x < w && rgb8) rgb8[((size_t)r * w + x) * 3] = (unsigned char)mr_cast_u8(o0 + o1 + o2);\n    if (0) {\n";
-        else if (!strcmp(ex, "nocast")) s += "    if (x < w && rgb8) { const size_t p = ((size_t)r * w + x) * 3; rgb8[p] = (unsigned char)(int)o0; rgb8[p+1] = (unsigned char)(int)o1; rgb8[p+2] = (unsigned char)(int)o2; }\n    if (0) {\n";
-        else s += "    if (x < w) {\n";
-    } else
-    s += "    if (x < w) {\n";
-    s += "        const size_t p = ((size_t)r * w + x) * 3;\n"
-         "        if (rgb64) { rgb64[p] = o0; rgb64[p + 1] = o1; rgb64[p + 2] = o2; }\n"
-         "        if (rgb8) {\n"
-         "            rgb8[p] = (unsigned char)mr_cast_u8(o0);\n"
-         "            rgb8[p + 1] = (unsigned char)mr_cast_u8(o1);\n"
-         "            rgb8[p + 2] = (unsigned char)mr_cast_u8(o2);\n"
+    // RGB8: a wavefront's 64 pixels are 192 consecutive bytes.  When they are dword-aligned, lanes 0..47 each assemble
+    // one dword from the packed colours of two neighbouring lanes (two ds_bpermute) and the wave issues one coalesced
+    // store instead of three byte-strided ones.  Ragged ends and unaligned rows take the byte stores.
+    s += "    if (rgb64 && x < w) { const size_t p = ((size_t)r * w + x) * 3; rgb64[p] = o0; rgb64[p + 1] = o1; rgb64[p + 2] = o2; }\n"
+         "    if (rgb8) {\n"
+         "        const unsigned pk = mr_cast_u8(o0) | (mr_cast_u8(o1) << 8) | (mr_cast_u8(o2) << 16);\n"
+         "        const unsigned xw = x0 + (threadIdx.x & ~63u);                      // first pixel of this wavefront\n"
+         "        unsigned char *wave_out = rgb8 + ((size_t)r * w + xw) * 3;\n"
+         "        if (xw + 64u <= w && ((size_t)wave_out & 3u) == 0u) {                // wave-uniform\n"
+         "            const unsigned pa = (unsigned)__builtin_amdgcn_ds_bpermute((int)(mr_src * 4u), (int)pk);\n"
+         "            const unsigned pb = (unsigned)__builtin_amdgcn_ds_bpermute((int)(mr_src * 4u + 4u), (int)pk);\n"
+         "            const unsigned dw = (unsigned)((((unsigned long long)pb << 24) | pa) >> mr_shift);\n"
+         "            if (mr_lane < 48u) ((unsigned *)wave_out)[mr_lane] = dw;\n"
+         "        } else if (x < w) {\n"
+         "            unsigned char *q = rgb8 + ((size_t)r * w + x) * 3;\n"
+         "            q[0] = (unsigned char)pk; q[1] = (unsigned char)(pk >> 8); q[2] = (unsigned char)(pk >> 16);\n"
          "        }\n"
          "    }\n"
          "    }\n";
@@ -716,7 +726,7 @@ struct JitBackend final : Backend {
     unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;
     double *d_rgb64 = nullptr; size_t rgb64_cap = 0;
     hipStream_t own_stream = nullptr;
-    uint32_t n_row_chunks = 1, n_gwords = 0;
+    uint32_t n_row_chunks = 1, n_gwords = 0, n_gjobs = 0;
     unsigned long long *d_gbits = nullptr; size_t gbits_cap = 0;
     bool has_sin = false;               // some Sin argument is not proven bounded: tiles may be deferred to `slow`
 
@@ -756,7 +766,7 @@ struct JitBackend final : Backend {
             HIP_TRY(hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f_pix));
             if (scratch == 0 || getenv("MARAY_JIT_WAVES")) break;
         }
-        if (prog.n_row_ops) jit_compile(jit_source_rows(prog, &n_row_chunks), code_rows, log);
+        if (prog.n_row_ops) jit_compile(jit_source_rows(prog, &n_row_chunks, &n_gjobs), code_rows, log);
         slow = make_tape_backend(dev, prog, tex, n_tex, false);
         P = prog;
         P.consts = nullptr; P.row_ops = nullptr; P.pix_ops = nullptr;
@@ -789,19 +799,25 @@ struct JitBackend final : Backend {
         cap = n;
     }
 
-    void launch(uint32_t w, uint32_t y0, uint32_t y1, unsigned char *d8, double *d64, hipStream_t st, bool rows_pass) {
-        const uint32_t rows_total = y1 - y0;
+    void launch(uint32_t w, const RowBlocks &rb, unsigned char *d8, double *d64, hipStream_t st, bool rows_pass) {
+        const uint32_t rows_total = rb.n_rows, y0 = rb.y0;
+        unsigned blk_rows = rb.block_rows, blk_stride = rb.block_stride;
         if (!rows_total || !w) return;
         ensure(d_yvals, yvals_cap, (size_t)rows_total * std::max<uint32_t>(P.n_yvals, 1));
-        ensure(d_gbits, gbits_cap, (size_t)rows_total * ((w + 255) / 256) * std::max<uint32_t>(n_gwords, 1));
+        {
+            const size_t had = gbits_cap;
+            ensure(d_gbits, gbits_cap, (size_t)rows_total * ((w + 255) / 256) * std::max<uint32_t>(n_gwords, 1));
+            // bits past the last guard belong to no job and are never written: zero them once (the pixel kernel tests whole words)
+            if (gbits_cap != had) HIP_TRY(hipMemsetAsync(d_gbits, 0, gbits_cap * sizeof(unsigned long long), st));
+        }
         unsigned n_yvals = P.n_yvals;
         if (rows_pass && P.n_row_ops) {
             unsigned yy0 = y0, rr = rows_total, ww = w;
             unsigned n_tx_ = (w + 255) / 256;
             const uint64_t items = n_gwords ? (uint64_t)rows_total * n_tx_ : rows_total;     // guards: one per (row, 256-pixel tile)
             if ((items + 63) / 64 > 0x7FFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
-            void *args[] = {&d_yvals, &d_gbits, &d_tex, &yy0, &rr, &n_yvals, &ww, &n_tx_};
-            HIP_TRY(hipModuleLaunchKernel(f_rows, (unsigned)((items + 63) / 64), n_row_chunks + n_gwords, 1, 64, 1, 1, 0, st, args, nullptr));
+            void *args[] = {&d_yvals, &d_gbits, &d_tex, &yy0, &rr, &n_yvals, &ww, &n_tx_, &blk_rows, &blk_stride};
+            HIP_TRY(hipModuleLaunchKernel(f_rows, (unsigned)((items + 63) / 64), n_row_chunks + n_gjobs, 1, 64, 1, 1, 0, st, args, nullptr));
         }
         const unsigned n_tx = (w + 255) / 256;
         const uint64_t n_tiles = (uint64_t)n_tx * rows_total;
@@ -819,18 +835,18 @@ struct JitBackend final : Backend {
             double *p64 = d64 ? d64 + (size_t)r0 * w * 3 : nullptr;
             const double *yv = d_yvals + (size_t)r0 * n_yvals;
             unsigned *fl = d_flags;
-            unsigned ww = w, yy0 = y0 + r0, tile_base = r0 * gx;
+            unsigned ww = w, yy0 = y0, tile_base = r0 * gx, row_base = r0;
             const unsigned long long *gb = d_gbits + (size_t)r0 * n_tx * n_gwords;
             unsigned ntx = n_tx;
-            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles};
+            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles, &blk_rows, &blk_stride, &row_base};
             HIP_TRY(hipModuleLaunchKernel(f_pix, gx, rows, 1, 256, 1, 1, 0, st, args, nullptr));
         }
-        if (has_sin) slow->render_flagged(w, y0, y1, d8, d64, st, d_flags, d_yvals);   // no-op unless a tile was deferred
+        if (has_sin) slow->render_flagged(w, rb, d8, d64, st, d_flags, d_yvals);   // no-op unless a tile was deferred
     }
 
-    void render_device(uint32_t w, uint32_t, uint32_t y0, uint32_t y1, void *d8, void *d64, void *stream) override {
+    void render_device(uint32_t w, uint32_t, const RowBlocks &rb, void *d8, void *d64, void *stream) override {
         HIP_TRY(hipSetDevice(device));
-        launch(w, y0, y1, (unsigned char *)d8, (double *)d64, (hipStream_t)stream, true);
+        launch(w, rb, (unsigned char *)d8, (double *)d64, (hipStream_t)stream, true);
     }
 
     void render_host(uint32_t w, uint32_t, uint32_t y0, uint32_t y1, uint8_t *rgb8, double *rgb64) override {
@@ -838,7 +854,7 @@ struct JitBackend final : Backend {
         const size_t n = (size_t)(y1 - y0) * w * 3;
         if (rgb8) ensure(d_rgb8, rgb8_cap, n);
         if (rgb64) ensure(d_rgb64, rgb64_cap, n);
-        launch(w, y0, y1, rgb8 ? d_rgb8 : nullptr, rgb64 ? d_rgb64 : nullptr, own_stream, true);
+        launch(w, RowBlocks::range(y0, y1), rgb8 ? d_rgb8 : nullptr, rgb64 ? d_rgb64 : nullptr, own_stream, true);
         if (rgb8) HIP_TRY(hipMemcpyAsync(rgb8, d_rgb8, n, hipMemcpyDeviceToHost, own_stream));
         if (rgb64) HIP_TRY(hipMemcpyAsync(rgb64, d_rgb64, n * 8, hipMemcpyDeviceToHost, own_stream));
         HIP_TRY(hipStreamSynchronize(own_stream));
@@ -850,11 +866,11 @@ struct JitBackend final : Backend {
         unsigned char *p8 = (unsigned char *)d8;
         double *p64 = (double *)d64;
         if (!p8 && !p64) { ensure(d_rgb8, rgb8_cap, n); p8 = d_rgb8; }
-        launch(w, y0, y1, p8, p64, own_stream, true);
+        launch(w, RowBlocks::range(y0, y1), p8, p64, own_stream, true);
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, own_stream));
-        for (int i = 0; i < reps; i++) launch(w, y0, y1, p8, p64, own_stream, false);
+        for (int i = 0; i < reps; i++) launch(w, RowBlocks::range(y0, y1), p8, p64, own_stream, false);
         HIP_TRY(hipEventRecord(e1, own_stream));
         HIP_TRY(hipEventSynchronize(e1));
         float ms = 0.f;

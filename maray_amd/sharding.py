@@ -34,6 +34,19 @@ def interleaved_blocks(rank, world, h, block_rows):
     return [(y, min(h, y + block_rows)) for b, y in enumerate(range(0, h, block_rows)) if b % world == rank]
 
 
+def interleaved_layout(rank, world, h, block_rows):
+    """The same share as interleaved_blocks, as one regular pattern (y0, block_rows, block_stride, n_blocks) for
+    maray_hip_render_blocks_device -- or None when the last block is ragged and the blocks have to go one by one."""
+    blocks = interleaved_blocks(rank, world, h, block_rows)
+    if not blocks:
+        return None
+    if len(blocks) == 1:
+        return blocks[0][0], blocks[0][1] - blocks[0][0], 0, 1
+    if any(b - a != block_rows for a, b in blocks):
+        return None
+    return blocks[0][0], block_rows, world * block_rows, len(blocks)
+
+
 def max_over_ranks(dist, value, device=None):
     """MAX all-reduce of a python float (no-op when not initialised)."""
     import torch

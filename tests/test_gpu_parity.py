@@ -250,3 +250,44 @@ def test_jit_in_a_process_that_imported_torch_first(chess_bytes):
     assert out.returncode == 0, out.stderr[-2000:]
     name, digest = out.stdout.split()[-2:]
     assert name == 'maray_jit_pixels' and digest == g['rgb8_sha256']
+
+
+_BLOCKS_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path[:0] = [%(root)r, %(tests)r]
+import maray_amd as M
+from test_lowering import same_f64
+tape = M.Scene(open(%(scene)r, 'rb').read()).lower()
+w = h = 1024
+y0, br, stride, nb = 64, 32, 96, 9          # rows 64..95, 160..191, ... up to 832..863
+for b in (M.BACKEND_TAPE, M.BACKEND_TAPE_SMEM, M.BACKEND_JIT):
+    ctx = M.Context(tape, backend=b)
+    one8 = torch.zeros((nb * br, w, 3), dtype=torch.uint8, device='cuda')
+    one64 = torch.zeros((nb * br, w, 3), dtype=torch.float64, device='cuda')
+    ctx.render_blocks_device(w, h, y0, br, stride, nb, d_rgb8=one8.data_ptr(), d_rgb64=one64.data_ptr())
+    torch.cuda.synchronize()
+    for k in range(nb):
+        g8, g64 = ctx.render_rows(w, h, y0 + k * stride, y0 + k * stride + br)
+        assert np.array_equal(one8[k * br:(k + 1) * br].cpu().numpy(), g8), (b, k)
+        assert same_f64(one64[k * br:(k + 1) * br].cpu().numpy(), g64), (b, k)
+    for bad in ((0, 32, 16, 2), (900, 32, 96, 9)):       # overlapping blocks; blocks past the image
+        try:
+            ctx.render_blocks_device(w, h, *bad, d_rgb8=one8.data_ptr())
+        except M.MarayError:
+            pass
+        else:
+            raise AssertionError(bad)
+    ctx.close()
+print('blocks ok')
+"""
+
+
+def test_row_blocks_in_one_launch_equal_the_blocks_one_by_one():
+    """maray_hip_render_blocks_device: a rank's interleaved share (blocks of rows, a stride apart) in one launch.
+    Device buffers come from PyTorch, which has to be imported before the library: a process of its own."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = _BLOCKS_SCRIPT % dict(root=os.path.dirname(here), tests=here, scene=os.path.join(GOLDEN, 'chess.maray'))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and 'blocks ok' in out.stdout, out.stderr[-3000:]

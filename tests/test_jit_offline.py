@@ -63,6 +63,6 @@ def test_row_section_is_cut_into_chunks(chess_bytes):
     assert written == list(range(n_num)) and 0 < n_num < tape.info['n_yvals']
     n_guards = tape.info['n_yvals'] - n_num
     assert len(re.findall(r'gacc \|= ', guards_src)) == n_guards and 'yout[' not in guards_src.split('switch')[1]
-    assert guards_src.count('    case ') == (n_guards + 63) // 64
+    assert guards_src.count('    case ') == (n_guards + 15) // 16       # 16 guards per job: many short wavefronts
     assert 'XMIN' in guards_src and 'XMIN' not in rows_src.split('switch')[1]      # only guards depend on the span
     build(tape)        # compiles the ROW kernel as well

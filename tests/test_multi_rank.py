@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from maray_amd.sharding import interleaved_blocks, max_over_ranks, scene_scale, strong_rows, weak_rows
+from maray_amd.sharding import interleaved_blocks, interleaved_layout, max_over_ranks, scene_scale, strong_rows, weak_rows
 
 
 def test_row_ranges_partition_the_image():
@@ -36,7 +36,12 @@ def test_bench_sharding_is_a_balanced_partition():
             assert sum(b - a for a, b in blocks) == h // world   # equal rows per rank
             for a, b in blocks:
                 seen[a:b] += 1
+            # the same share as ONE launch of maray_hip_render_blocks_device
+            y0, br, stride, nb = interleaved_layout(r, world, h, 256)
+            assert [(y0 + k * stride, y0 + k * stride + br) for k in range(nb)] == blocks
         assert (seen == 1).all()                                  # every row exactly once
+    assert interleaved_layout(1, 2, 1000, 256) is None           # ragged last block: no regular pattern
+    assert interleaved_layout(0, 1, 1000, 256) == (0, 1000, 0, 1)
     assert [scene_scale(n) for n in (1, 2, 4, 8)] == [(4, 4), (8, 4), (8, 8), (16, 8)]
 
 
