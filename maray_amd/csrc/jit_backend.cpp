@@ -175,7 +175,7 @@ struct Emitter {
 
         struct Open { uint32_t end; bool as_bool; bool nz; };
         std::vector<Open> open;     // SKIPZ / SKIPNZ regions being emitted, innermost last
-        std::vector<uint8_t> forced(n, 0);      // op is the end of a region known to be skipped: its value is the constant 0
+        std::vector<uint8_t> forced(n, 0);      // op ends a region known at compile time to be skipped: its value is 0 (1) or 1 (2)
         for (uint32_t i = 0; i < n; i++) {
             const uint64_t ins = ops[i];
             const uint32_t op = MARAY_INS_OP(ins), aux = MARAY_INS_AUX(ins), dst = MARAY_INS_DST(ins);
@@ -197,6 +197,11 @@ struct Emitter {
                     forced[end] = 1;            // nothing of the region is emitted; op `end` becomes the constant
                     i = end - 1;
                     continue;
+                }
+                if (!row_guard && va->kind == BOOL && (va->b == "MR_NONE" || va->b == "MR_ALL")) {
+                    // the guard is a literal (it followed from regions skipped above): decide here
+                    if ((va->b == "MR_NONE") != nz) { forced[end] = nz ? 2 : 1; i = end - 1; }     // taken: the region is never emitted
+                    continue;                                                                    // not taken: an evaluator may ignore a SKIP op
                 }
                 if (row_guard && !nz && guard_words && MARAY_REF_INDEX(gref) >= guard_first) {
                     // a row bound: one bit of a guard word that sits in an SGPR since the kernel's prologue
@@ -254,9 +259,8 @@ struct Emitter {
             auto m_not = [](const std::string &a) -> std::string {
                 return a == "MR_NONE" ? "MR_ALL" : (a == "MR_ALL" ? "MR_NONE" : "~" + a);
             };
-            if (forced[i]) {
-                if (i < bool_hint.size() && bool_hint[i]) be = "MR_NONE"; else e = "0.0";
-            } else
+            if (forced[i]) be = forced[i] == 2 ? "MR_ALL" : "MR_NONE";     // exactly +0.0 / 1.0: a boolean whatever the op
+            else
             switch (op) {
             case MARAY_OP_MOV: r = *va; break;
             case MARAY_OP_NEG:
@@ -312,7 +316,7 @@ struct Emitter {
                     out += "    b" + self + " = mr_ballot((" + e + ") != 0.0);\n    } else b" + self + (o.nz ? " = MR_ALL;\n" : " = MR_NONE;\n");
                     r.kind = BOOL; r.b = "b" + self;
                 } else {
-                    const std::string ee = !e.empty() ? e : "mr_pos(" + be + ")";
+                    const std::string ee = !e.empty() ? e : (be == "MR_NONE" ? "0.0" : be == "MR_ALL" ? "1.0" : "mr_pos(" + be + ")");
                     out += "    " + self + " = " + ee + ";\n    } else " + self + (o.nz ? " = 1.0;\n" : " = 0.0;\n");
                     r.kind = DBL; r.d = self;
                 }
