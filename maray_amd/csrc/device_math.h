@@ -68,9 +68,9 @@ MARAY_DEV unsigned mr_cast_u8(double v)
 // Rust `f64 as u32` (src/textures.rs:32-33): saturating, NaN -> 0.
 MARAY_DEV unsigned mr_cast_u32(double v)
 {
-    if (!(v > 0.0)) return 0u;
-    if (v >= 4294967295.0) return 4294967295u;
-    return (unsigned)v;
+    unsigned u;
+    asm("v_cvt_u32_f64 %0, %1" : "=v"(u) : "v"(v));      // see mr_cast_u8
+    return u;
 }
 
 struct MarayTex {
