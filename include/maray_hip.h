@@ -92,7 +92,8 @@ typedef struct maray_lower_opts {
                               SKIP op, unconditionally); 0 = each row region re-derives the x-dependent values it reads (default) */
     uint32_t no_rebalance; /* 1 = keep chains of one boolean connective (max(t1, max(t2, ...))) as written; 0 = rebuild them as
                               balanced trees, whose sub-trees get row-level SKIP ops of their own (default) */
-    uint32_t reserved[1];
+    uint32_t no_y_spans;   /* 1 = guards bound a boolean over a span of x on one row only (they read Y); 0 = guards monotone in y
+                              too are bounded over the rows [YMIN, YMAX] as well, i.e. over a rectangle of pixels (default) */
 } maray_lower_opts;
 
 typedef struct maray_tape_info {

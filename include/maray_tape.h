@@ -38,6 +38,10 @@
  *                 proves the boolean 0 for every x in [XMIN, XMAX]); y values read as operands never
  *                 do.  An evaluator that runs the ROW section once per row passes 0 and w - 1; one
  *                 that evaluates the guards per tile of a row passes the tile's ends and skips more.
+ *                 5 = YMAX, 6 = YMIN (ROW section only): the same for rows.  A guard whose cone reads
+ *                 YMIN / YMAX and not Y holds for every pixel of [XMIN, XMAX] x [YMIN, YMAX]; an
+ *                 evaluator may compute it once for several rows.  A guard that reads Y is exact
+ *                 for that row and valid for that row only.  Evaluating per row: YMIN = YMAX = Y.
  *
  * Every op also leaves its result in ACC.  An op with dst == MARAY_DST_NONE
  * is consumed only through ACC by the next op.
@@ -47,7 +51,7 @@
 
 #include <stdint.h>
 
-#define MARAY_TAPE_VERSION 2u   /* 2: SPEC XMIN */
+#define MARAY_TAPE_VERSION 2u   /* 2: SPEC XMIN, YMAX, YMIN */
 
 enum {
     MARAY_OP_NOP = 0,
@@ -91,7 +95,7 @@ enum {
 #define MARAY_MAX_INDEX 0x3FFFu
 
 enum { MARAY_K_SLOT = 0, MARAY_K_CONST = 1, MARAY_K_YVAL = 2, MARAY_K_SPEC = 3 };
-enum { MARAY_SPEC_X = 0, MARAY_SPEC_Y = 1, MARAY_SPEC_ACC = 2, MARAY_SPEC_XMAX = 3, MARAY_SPEC_XMIN = 4 };
+enum { MARAY_SPEC_X = 0, MARAY_SPEC_Y = 1, MARAY_SPEC_ACC = 2, MARAY_SPEC_XMAX = 3, MARAY_SPEC_XMIN = 4, MARAY_SPEC_YMAX = 5, MARAY_SPEC_YMIN = 6 };
 
 #define MARAY_REF(kind, index) ((uint32_t)(((kind) << 14) | ((index) & 0x3FFFu)))
 #define MARAY_REF_KIND(r) (((r) >> 14) & 3u)

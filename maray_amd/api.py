@@ -40,7 +40,7 @@ class Texture(C.Structure):
 
 class LowerOpts(C.Structure):
     _fields_ = [('hoist_rows', C.c_uint32), ('plain_cse', C.c_uint32), ('no_fuse', C.c_uint32), ('no_skips', C.c_uint32), ('no_row_guards', C.c_uint32),
-                ('no_private_regions', C.c_uint32), ('no_rebalance', C.c_uint32), ('reserved', C.c_uint32 * 1)]
+                ('no_private_regions', C.c_uint32), ('no_rebalance', C.c_uint32), ('no_y_spans', C.c_uint32)]
 
 
 class CtxOpts(C.Structure):
@@ -202,14 +202,16 @@ class Scene:
     def rescale(self, sx, sy):
         _check(lib().maray_scene_rescale(self._h, sx, sy))
 
-    def lower(self, hoist_rows=True, plain_cse=False, fuse=True, skips=True, row_guards=True, private_regions=True, rebalance=True):
-        return Tape(self, hoist_rows, plain_cse, fuse, skips, row_guards, private_regions, rebalance)
+    def lower(self, hoist_rows=True, plain_cse=False, fuse=True, skips=True, row_guards=True, private_regions=True, rebalance=True,
+              y_spans=True):
+        return Tape(self, hoist_rows, plain_cse, fuse, skips, row_guards, private_regions, rebalance, y_spans)
 
 
 class Tape:
     """Lowered program (include/maray_tape.h)."""
 
-    def __init__(self, scene, hoist_rows=True, plain_cse=False, fuse=True, skips=True, row_guards=True, private_regions=True, rebalance=True):
+    def __init__(self, scene, hoist_rows=True, plain_cse=False, fuse=True, skips=True, row_guards=True, private_regions=True, rebalance=True,
+                 y_spans=True):
         o = LowerOpts()
         o.hoist_rows = 1 if hoist_rows else 0
         o.plain_cse = 1 if plain_cse else 0
@@ -218,6 +220,7 @@ class Tape:
         o.no_row_guards = 0 if row_guards else 1
         o.no_private_regions = 0 if private_regions else 1
         o.no_rebalance = 0 if rebalance else 1
+        o.no_y_spans = 0 if y_spans else 1
         h = C.c_void_p()
         _check(lib().maray_lower(scene._h, C.byref(o), C.byref(h)))
         self._h = h

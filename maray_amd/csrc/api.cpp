@@ -113,8 +113,8 @@ void validate_program(const maray_program &p)
                 case MARAY_K_SLOT: ok = idx < n_slots && written[idx]; break;
                 case MARAY_K_CONST: ok = idx < p.n_consts; break;
                 case MARAY_K_YVAL: ok = pixel && idx < p.n_yvals; break;
-                default: ok = idx <= MARAY_SPEC_XMIN && (idx != MARAY_SPEC_ACC || have_acc) && (idx != MARAY_SPEC_X || pixel) &&
-                              ((idx != MARAY_SPEC_XMAX && idx != MARAY_SPEC_XMIN) || !pixel);
+                default: ok = idx <= MARAY_SPEC_YMIN && (idx != MARAY_SPEC_ACC || have_acc) && (idx != MARAY_SPEC_X || pixel) &&
+                              (idx < MARAY_SPEC_XMAX || !pixel);      // the span specials are for the ROW section
                 }
                 if (!ok) throw Error{MARAY_E_ARG, "operand out of range or read before write at op " + std::to_string(i)};
             }

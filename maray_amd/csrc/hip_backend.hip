@@ -78,6 +78,7 @@ __device__ __forceinline__ void run_tape(const KArgs &A, const uint64_t *tape_ld
         if (kind == MARAY_K_CONST) return TAPE_LDS ? consts_lds[idx] : consts_k[idx];
         if (kind == MARAY_K_YVAL) return yrow_k[idx];
         // guards are evaluated once per row here: the span is the whole row, XMIN = 0 and XMAX = w - 1
+        if (idx == MARAY_SPEC_YMAX || idx == MARAY_SPEC_YMIN) return Y;     // ... and one row at a time
         return idx == MARAY_SPEC_X ? X : (idx == MARAY_SPEC_Y ? Y : (idx == MARAY_SPEC_ACC ? acc : (idx == MARAY_SPEC_XMAX ? (double)(A.w - 1u) : 0.0)));
     };
 

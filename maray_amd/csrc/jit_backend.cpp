@@ -156,7 +156,8 @@ struct Emitter {
             case MARAY_K_YVAL: t.d = yv_name + "[" + std::to_string(idx) + "]"; return &t;
             default:
                 if (idx == MARAY_SPEC_ACC) return &vals[acc];
-                t.d = idx == MARAY_SPEC_X ? "X" : (idx == MARAY_SPEC_Y ? "Y" : (idx == MARAY_SPEC_XMAX ? "XMAX" : "XMIN"));
+                static const char *const spec_name[] = {"X", "Y", "", "XMAX", "XMIN", "YMAX", "YMIN"};
+                t.d = spec_name[idx];
                 return &t;
             }
         };
@@ -231,7 +232,7 @@ struct Emitter {
             if (op == MARAY_OP_OUT) {
                 const std::string a = dbl(va, "m", i, 0);
                 if (!pixel && out_guard_bits && aux >= guard_first)
-                    out += "    gacc |= (" + a + " != 0.0) ? (1ull << " + std::to_string((aux - guard_first) % 16) + ") : 0ull;\n";
+                    out += "    gacc |= (" + a + " != 0.0) ? (1ull << " + std::to_string((aux - guard_first) % 8) + ") : 0ull;\n";
                 else
                     out += pixel ? "    o" + std::to_string(aux) + " = " + a + ";\n"
                                  : "    yout[" + std::to_string(aux) + "] = " + a + ";\n";
@@ -355,6 +356,7 @@ struct Emitter {
 struct RowTapeDeps {
     std::vector<std::array<int32_t, 2>> deps;   // per op: the ops that produce its operands (-1: none)
     std::vector<uint32_t> outs;                 // OUT ops, tape order
+    std::vector<uint8_t> reads_y;               // per op: SPEC Y is somewhere in its cone
 };
 
 RowTapeDeps row_tape_deps(const maray_program &P)
@@ -362,6 +364,8 @@ RowTapeDeps row_tape_deps(const maray_program &P)
     const uint32_t n = P.n_row_ops;
     RowTapeDeps d;
     d.deps.assign(n, {-1, -1});
+    d.reads_y.assign(n, 0);
+    auto is_y = [](uint32_t ref) { return MARAY_REF_KIND(ref) == MARAY_K_SPEC && MARAY_REF_INDEX(ref) == MARAY_SPEC_Y; };
     std::vector<int32_t> slot_writer(P.n_row_slots ? P.n_row_slots : 1, -1);
     int32_t acc = -1;
     auto producer = [&](uint32_t ref) -> int32_t {
@@ -374,10 +378,16 @@ RowTapeDeps row_tape_deps(const maray_program &P)
         const uint64_t ins = P.row_ops[j];
         const uint32_t op = MARAY_INS_OP(ins);
         if (op == MARAY_OP_NOP) continue;
-        if (op != MARAY_OP_TEXDIM) d.deps[j][0] = producer(MARAY_INS_A(ins));
+        if (op != MARAY_OP_TEXDIM) {
+            d.deps[j][0] = producer(MARAY_INS_A(ins));
+            d.reads_y[j] = is_y(MARAY_INS_A(ins)) || (d.deps[j][0] >= 0 && d.reads_y[d.deps[j][0]]);
+        }
         if (op == MARAY_OP_SKIPZ || op == MARAY_OP_SKIPNZ) continue;        // reads its guard, leaves ACC and the slots alone
         if (op == MARAY_OP_OUT) { d.outs.push_back(j); continue; }
-        if (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) d.deps[j][1] = producer(MARAY_INS_B(ins));
+        if (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) {
+            d.deps[j][1] = producer(MARAY_INS_B(ins));
+            d.reads_y[j] |= is_y(MARAY_INS_B(ins)) || (d.deps[j][1] >= 0 && d.reads_y[d.deps[j][1]]);
+        }
         acc = (int32_t)j;
         if (MARAY_INS_DST(ins) != MARAY_DST_NONE) slot_writer[MARAY_INS_DST(ins)] = (int32_t)j;
     }
@@ -444,13 +454,25 @@ uint32_t jit_guard_words(const maray_program &P)
     return (jit_row_guards_enabled() && nw <= 12) ? nw : 0;
 }
 
+// Rows per guard evaluation: 8 when no guard's cone reads Y (every guard then bounds its boolean over the rows
+// [YMIN, YMAX] too, include/maray_tape.h), else 1.
+uint32_t jit_guard_rows(const maray_program &P)
+{
+    if (!jit_guard_words(P)) return 1;
+    const RowTapeDeps d = row_tape_deps(P);
+    const uint32_t n_ynum = numeric_yvals(P);
+    for (uint32_t o : d.outs) if (MARAY_INS_AUX(P.row_ops[o]) >= n_ynum && d.reads_y[o]) return 1;
+    return 8;
+}
+
 // Source of the ROW kernel, maray_jit_rows: one wavefront per block, blockIdx.y picks the job.
 //  y < n_chunks: chunk y of the ROW section, one work-item per row; writes the y values the pixel
 //    kernel reads as operands (and, for a program that may defer tiles to the interpreter, the
 //    guards too, bounded over the whole row as the interpreter expects).
-//  y >= n_chunks: guards 16 (y - n_chunks) .. +15, one work-item per (row, 256-pixel tile),
-//    evaluated with XMIN / XMAX = the tile's ends (a bound over 256 pixels skips far more than
-//    one over the row); writes its 16 bits of the tile's guard words (64 guards per word).  Small
+//  y >= n_chunks: guards 8 (y - n_chunks) .. +7, one work-item per (group of `yrows` rows,
+//    256-pixel tile), evaluated with XMIN / XMAX = the tile's ends and YMIN / YMAX = the group's
+//    (a bound over 256 x 8 pixels skips far more than one over the row); writes its byte of
+//    the rectangle's guard words (64 guards per word).  yrows = 1 when some guard reads Y.  Small
 //    jobs on purpose: each is one long dependent chain, and only more wavefronts hide that.
 // One launch for both: the few y-value wavefronts run in the shadow of the guard ones.
 // Plain device_math.h: the rare huge-argument tail of sin is a real (out-of-line) call here.
@@ -460,7 +482,7 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
     Emitter E(P);
     const RowTapeDeps deps = row_tape_deps(P);
     const uint32_t n_ynum = numeric_yvals(P), n_gwords = jit_guard_words(P);
-    const uint32_t n_gjobs = n_gwords ? (P.n_yvals - n_ynum + 15) / 16 : 0;       // 16 guards = a quarter of a word per job
+    const uint32_t n_gjobs = n_gwords ? (P.n_yvals - n_ynum + 7) / 8 : 0;       // 8 guards = one byte of a word per job
     if (n_gjobs_out) *n_gjobs_out = n_gjobs;
     // the interpreter (which drains deferred tiles from the same y-value table) does read the guard values
     const uint32_t out_limit = may_defer_tiles(P) ? 0xFFFFFFFFu : n_ynum;
@@ -470,18 +492,19 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
     s += "// generated by libmaray_hip (jit_backend.cpp): ROW section, " + std::to_string(P.n_row_ops) + " ops; y values in " +
          std::to_string(chunks.size()) + " chunks, " + std::to_string(P.n_yvals - n_ynum) + " guards in " + std::to_string(n_gwords) + " words\n";
     s += "#include \"device_math.h\"\n\n";
-    s += "extern \"C\" __global__ void __launch_bounds__(64) maray_jit_rows(double *__restrict__ yvals, unsigned long long *__restrict__ gbits,\n"
+    s += "extern \"C\" __global__ void __launch_bounds__(256) maray_jit_rows(double *__restrict__ yvals, unsigned long long *__restrict__ gbits,\n"
          "                                                                 const MarayTex *__restrict__ tex,\n"
          "                                                                 unsigned y0, unsigned rows, unsigned n_yvals, unsigned w, unsigned n_tx,\n"
-         "                                                                 unsigned blk_rows, unsigned blk_stride)\n{\n"
-         "    const unsigned long long item = (unsigned long long)blockIdx.x * 64u + threadIdx.x;\n"
+         "                                                                 unsigned blk_rows, unsigned blk_stride, unsigned yrows)\n{\n"
+         "    const unsigned long long item = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;\n"
          "    (void)tex; (void)gbits; (void)n_tx;\n"
          "    if (blockIdx.y < " + std::to_string(chunks.size()) + "u) {\n"
          "    if (item >= rows) return;\n"
          "    const unsigned r = (unsigned)item;\n"
          "    const double Y = (double)(y0 + (r / blk_rows) * blk_stride + r % blk_rows), XMIN = 0.0, XMAX = (double)(w - 1u);\n"
+         "    const double YMIN = Y, YMAX = Y;\n"
          "    double *yout = yvals + (size_t)r * n_yvals;\n"
-         "    (void)Y; (void)XMIN; (void)XMAX; (void)yout;\n"
+         "    (void)Y; (void)XMIN; (void)XMAX; (void)YMIN; (void)YMAX; (void)yout; (void)yrows;\n"
          "    switch (blockIdx.y) {\n";
     for (size_t k = 0; k < chunks.size(); k++) {
         s += "    case " + std::to_string(k) + ": {\n";
@@ -490,14 +513,18 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
     }
     s += "    }\n    return;\n    }\n";
     if (n_gwords) {
-        s += "    // guards: (row, tile), the tiles of a row adjacent\n"
-             "    if (item >= (unsigned long long)rows * n_tx) return;\n"
-             "    const unsigned r = (unsigned)(item / n_tx), tile = (unsigned)(item % n_tx);\n"
+        s += "    // guards: (row group, tile), the tiles of a group adjacent\n"
+             "    const unsigned n_groups = (rows + yrows - 1u) / yrows;\n"
+             "    if (item >= (unsigned long long)n_groups * n_tx) return;\n"
+             "    const unsigned grp = (unsigned)(item / n_tx), tile = (unsigned)(item % n_tx);\n"
+             "    const unsigned r = grp * yrows, r_last = r + yrows - 1u < rows - 1u ? r + yrows - 1u : rows - 1u;      // launch rows of the group\n"
              "    const unsigned xlo = tile * 256u, xhi = xlo + 255u < w - 1u ? xlo + 255u : w - 1u;\n"
+             "    // a group never straddles two row blocks (the host picks yrows | blk_rows), so its image rows are consecutive\n"
              "    const double Y = (double)(y0 + (r / blk_rows) * blk_stride + r % blk_rows), XMIN = (double)xlo, XMAX = (double)xhi;\n"
+             "    const double YMIN = Y, YMAX = Y + (double)(r_last - r);\n"
              "    unsigned long long gacc = 0ull;\n"
              "    double *yout = nullptr;\n"
-             "    (void)Y; (void)XMIN; (void)XMAX; (void)yout;\n"
+             "    (void)Y; (void)XMIN; (void)XMAX; (void)YMIN; (void)YMAX; (void)yout;\n"
              "    switch (blockIdx.y - " + std::to_string(chunks.size()) + "u) {\n";
         E.out_guard_bits = true;
         E.guard_first = n_ynum;
@@ -505,7 +532,7 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
             std::vector<uint32_t> outs;
             for (uint32_t o : deps.outs) {
                 const uint32_t aux = MARAY_INS_AUX(P.row_ops[o]);
-                if (aux >= n_ynum + 16 * j && aux < n_ynum + 16 * (j + 1)) outs.push_back(o);
+                if (aux >= n_ynum + 8 * j && aux < n_ynum + 8 * (j + 1)) outs.push_back(o);
             }
             const std::vector<uint64_t> tape = row_tape_cone(P, deps, outs, nullptr);
             s += "    case " + std::to_string(j) + ": {\n";
@@ -513,7 +540,7 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
             s += "    } break;\n";
         }
         s += "    }\n"
-             "    ((unsigned short *)gbits)[item * " + std::to_string(4 * n_gwords) + "u + (blockIdx.y - " + std::to_string(chunks.size()) + "u)] = (unsigned short)gacc;\n";
+             "    ((unsigned char *)gbits)[item * " + std::to_string(8 * n_gwords) + "u + (blockIdx.y - " + std::to_string(chunks.size()) + "u)] = (unsigned char)gacc;\n";
     }
     s += "}\n";
     return s;
@@ -565,7 +592,7 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
          "                                                                    unsigned *__restrict__ tile_list, unsigned tile_base,\n"
          "                                                                    const unsigned long long *__restrict__ gbits, unsigned n_tx,\n"
          "                                                                    unsigned w, unsigned y0, unsigned n_yvals, unsigned tiles,\n"
-         "                                                                    unsigned blk_rows, unsigned blk_stride, unsigned row_base)\n{\n"
+         "                                                                    unsigned blk_rows, unsigned blk_stride, unsigned row_base, unsigned yrows)\n{\n"
          "    const unsigned r = blockIdx.y;                     // row of this launch; row_base + r = row of the whole call\n"
          "    const double *yrow = yvals + (size_t)r * n_yvals;\n";
     if (defer) s += "    if (threadIdx.x == 0) mr_slow_tile = 0u;\n";
@@ -580,7 +607,7 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
     if (E.guard_words) {
         const std::string nw = std::to_string(E.guard_words);
         s += "    const unsigned tile0 = blockIdx.x * tiles, my_tiles = n_tx - tile0 < tiles ? n_tx - tile0 : tiles;\n"
-             "    const unsigned long long gs = threadIdx.x < my_tiles * " + nw + "u ? gbits[((size_t)r * n_tx + tile0) * " + nw + "u + threadIdx.x] : 0ull;\n";
+             "    const unsigned long long gs = threadIdx.x < my_tiles * " + nw + "u ? gbits[((size_t)((row_base + r) / yrows) * n_tx + tile0) * " + nw + "u + threadIdx.x] : 0ull;\n";
     }
     for (uint32_t k = 0; k < y_rounds; k++) {
         const std::string i = std::to_string(k * 256) + "u + threadIdx.x";
@@ -591,7 +618,7 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
          "    const double Y = (double)(y0 + ((row_base + r) / blk_rows) * blk_stride + (row_base + r) % blk_rows);     // -> image row (RowBlocks)\n"
          "    mr_kptr yv = (mr_kptr)yrow;\n"
          "    const __attribute__((address_space(4))) unsigned *yw = (const __attribute__((address_space(4))) unsigned *)yv;\n"
-         "    (void)Y; (void)yv; (void)yw; (void)tex; (void)gbits; (void)n_tx;\n";
+         "    (void)Y; (void)yv; (void)yw; (void)tex; (void)gbits; (void)n_tx; (void)yrows;\n";
     s += "    const unsigned mr_lane = threadIdx.x & 63u;                              // dword mr_lane of a wave's RGB8 run starts\n"
          "    const unsigned mr_src = (mr_lane * 4u) / 3u, mr_shift = ((mr_lane * 4u) % 3u) * 8u;   // in pixel mr_src, mr_shift bits in\n"
          "    for (unsigned t = 0; t < tiles; t++) {\n"
@@ -730,7 +757,7 @@ struct JitBackend final : Backend {
     unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;
     double *d_rgb64 = nullptr; size_t rgb64_cap = 0;
     hipStream_t own_stream = nullptr;
-    uint32_t n_row_chunks = 1, n_gwords = 0, n_gjobs = 0;
+    uint32_t n_row_chunks = 1, n_gwords = 0, n_gjobs = 0, guard_rows = 1;
     unsigned long long *d_gbits = nullptr; size_t gbits_cap = 0;
     bool has_sin = false;               // some Sin argument is not proven bounded: tiles may be deferred to `slow`
 
@@ -778,6 +805,7 @@ struct JitBackend final : Backend {
             HIP_TRY(hipModuleLoadData(&mod_rows, code_rows.data()));
             HIP_TRY(hipModuleGetFunction(&f_rows, mod_rows, "maray_jit_rows"));
             n_gwords = jit_guard_words(prog);
+            guard_rows = jit_guard_rows(prog);
 
         }
         HIP_TRY(hipStreamCreate(&own_stream));
@@ -807,10 +835,13 @@ struct JitBackend final : Backend {
         const uint32_t rows_total = rb.n_rows, y0 = rb.y0;
         unsigned blk_rows = rb.block_rows, blk_stride = rb.block_stride;
         if (!rows_total || !w) return;
+        // rows per guard evaluation: a group must not straddle two row blocks (its image rows have to be consecutive)
+        unsigned yrows = (guard_rows > 1 && blk_rows % guard_rows == 0) ? guard_rows : 1u;
+        const uint32_t n_groups = (rows_total + yrows - 1) / yrows;
         ensure(d_yvals, yvals_cap, (size_t)rows_total * std::max<uint32_t>(P.n_yvals, 1));
         {
             const size_t had = gbits_cap;
-            ensure(d_gbits, gbits_cap, (size_t)rows_total * ((w + 255) / 256) * std::max<uint32_t>(n_gwords, 1));
+            ensure(d_gbits, gbits_cap, (size_t)n_groups * ((w + 255) / 256) * std::max<uint32_t>(n_gwords, 1));
             // bits past the last guard belong to no job and are never written: zero them once (the pixel kernel tests whole words)
             if (gbits_cap != had) HIP_TRY(hipMemsetAsync(d_gbits, 0, gbits_cap * sizeof(unsigned long long), st));
         }
@@ -818,10 +849,15 @@ struct JitBackend final : Backend {
         if (rows_pass && P.n_row_ops) {
             unsigned yy0 = y0, rr = rows_total, ww = w;
             unsigned n_tx_ = (w + 255) / 256;
-            const uint64_t items = n_gwords ? (uint64_t)rows_total * n_tx_ : rows_total;     // guards: one per (row, 256-pixel tile)
-            if ((items + 63) / 64 > 0x7FFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
-            void *args[] = {&d_yvals, &d_gbits, &d_tex, &yy0, &rr, &n_yvals, &ww, &n_tx_, &blk_rows, &blk_stride};
-            HIP_TRY(hipModuleLaunchKernel(f_rows, (unsigned)((items + 63) / 64), n_row_chunks + n_gjobs, 1, 64, 1, 1, 0, st, args, nullptr));
+            // guards: one item per (group of yrows rows, 256-pixel tile); y values: one per row
+            const uint64_t items = std::max<uint64_t>(n_gwords ? (uint64_t)n_groups * n_tx_ : 0, rows_total);
+            // Every job is a straight-line pass over its own code, executed once per wavefront: what bounds this kernel
+            // is instruction fetch, and the waves of one block share it.  MARAY_JIT_ROW_BLOCK: tuning knob.
+            unsigned bs = 256;
+            if (const char *e_ = getenv("MARAY_JIT_ROW_BLOCK")) if (atoi(e_) >= 64 && atoi(e_) <= 256 && atoi(e_) % 64 == 0) bs = (unsigned)atoi(e_);
+            if ((items + bs - 1) / bs > 0x7FFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
+            void *args[] = {&d_yvals, &d_gbits, &d_tex, &yy0, &rr, &n_yvals, &ww, &n_tx_, &blk_rows, &blk_stride, &yrows};
+            HIP_TRY(hipModuleLaunchKernel(f_rows, (unsigned)((items + bs - 1) / bs), n_row_chunks + n_gjobs, 1, bs, 1, 1, 0, st, args, nullptr));
         }
         const unsigned n_tx = (w + 255) / 256;
         const uint64_t n_tiles = (uint64_t)n_tx * rows_total;
@@ -840,9 +876,9 @@ struct JitBackend final : Backend {
             const double *yv = d_yvals + (size_t)r0 * n_yvals;
             unsigned *fl = d_flags;
             unsigned ww = w, yy0 = y0, tile_base = r0 * gx, row_base = r0;
-            const unsigned long long *gb = d_gbits + (size_t)r0 * n_tx * n_gwords;
+            const unsigned long long *gb = d_gbits;              // indexed by the row of the whole call
             unsigned ntx = n_tx;
-            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles, &blk_rows, &blk_stride, &row_base};
+            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles, &blk_rows, &blk_stride, &row_base, &yrows};
             HIP_TRY(hipModuleLaunchKernel(f_pix, gx, rows, 1, 256, 1, 1, 0, st, args, nullptr));
         }
         if (has_sin) slow->render_flagged(w, rb, d8, d64, st, d_flags, d_yvals);   // no-op unless a tile was deferred

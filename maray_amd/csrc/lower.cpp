@@ -31,7 +31,7 @@ namespace maray {
 
 namespace {
 
-enum : uint8_t { D_CONST = 100, D_X = 101, D_Y = 102, D_XMAX = 103, D_XMIN = 104 };   // leaf kinds; ops use MARAY_OP_*  (XMIN, XMAX: ends of the span of x a guard bounds)
+enum : uint8_t { D_CONST = 100, D_X = 101, D_Y = 102, D_XMAX = 103, D_XMIN = 104, D_YMAX = 105, D_YMIN = 106 };   // leaf kinds; ops use MARAY_OP_*  (XMIN..YMAX: the rectangle of pixels a guard bounds)
 enum : uint8_t { DEP_X = 1, DEP_Y = 2 };
 
 struct DNode {
@@ -245,7 +245,7 @@ std::vector<Ival> intervals(const Dag &g)
         Ival r{-INFINITY, INFINITY, true};
         switch (d.op) {
         case D_CONST: r = (d.cval != d.cval) ? Ival{-INFINITY, INFINITY, true} : Ival{d.cval, d.cval, false}; break;
-        case D_X: case D_Y: case D_XMAX: case D_XMIN: r = Ival{0.0, dmax, false}; break;
+        case D_X: case D_Y: case D_XMAX: case D_XMIN: case D_YMAX: case D_YMIN: r = Ival{0.0, dmax, false}; break;
         case MARAY_OP_MOV: r = a; break;
         case MARAY_OP_NEG: r = Ival{-a.hi, -a.lo, a.nan}; break;
         case MARAY_OP_ABS:
@@ -297,16 +297,17 @@ inline Mono join(Mono a, Mono b)     // both operands vary together (add / min /
     return M_NONE;
 }
 
-std::vector<Mono> monotonicity(const Dag &g, const std::vector<Ival> &iv)
+// Monotonicity in one coordinate (dep_bit / var_leaf = DEP_X / D_X or DEP_Y / D_Y) with everything else held fixed.
+std::vector<Mono> monotonicity(const Dag &g, const std::vector<Ival> &iv, uint8_t dep_bit = DEP_X, uint8_t var_leaf = D_X)
 {
     std::vector<Mono> m(g.n.size(), M_NONE);
     for (size_t i = 0; i < g.n.size(); i++) {
         const DNode &d = g.n[i];
-        if (!(d.dep & DEP_X)) { m[i] = M_CONSTX; continue; }
+        if (!(d.dep & dep_bit)) { m[i] = M_CONSTX; continue; }
         if (iv[i].nan) { m[i] = M_NONE; continue; }
         const Mono a = d.a >= 0 ? m[d.a] : M_NONE, b = d.b >= 0 ? m[d.b] : M_NONE;
+        if (d.op == var_leaf) { m[i] = M_INC; continue; }
         switch (d.op) {
-        case D_X: m[i] = M_INC; break;
         case MARAY_OP_MOV: case MARAY_OP_STEP: m[i] = a; break;
         case MARAY_OP_NEG: m[i] = flip(a); break;
         case MARAY_OP_SQRT: m[i] = iv[d.a].lo >= 0 ? a : M_NONE; break;
@@ -329,25 +330,33 @@ std::vector<Mono> monotonicity(const Dag &g, const std::vector<Ival> &iv)
     return m;
 }
 
-// Builds, for boolean nodes, y-only boolean expressions that bound them over a whole row:
-//   ub(v)(y) == 0  =>  v(x, y) == 0 for every pixel x in [0, w)        (lb: == 1 => v == 1)
-// A monotone boolean takes its extreme values at the end points of the span, x = XMIN and x = XMAX
-// (the whole row, 0 and w-1, or any part of it: monotone on the domain is monotone on a sub-interval).
+// Builds, for boolean nodes, boolean expressions free of one coordinate that bound them over a span of it:
+//   ub(v) == 0  =>  v == 0 for every value of the coordinate in [lo, hi]        (lb: == 1 => v == 1)
+// A monotone boolean takes its extreme values at the ends of the span (monotone on the domain is monotone on any
+// sub-interval).  Applied to x with lo / hi = XMIN / XMAX it gives the row guards; applied once more, to y with
+// YMIN / YMAX, to those guards, it gives guards that hold over a rectangle of pixels.
 struct RowBounds {
+    struct B { int32_t ub, lb; bool lossy; };       // lossy: somewhere below, a sub-expression could only be bounded by "anything"
     Dag &g;
     const std::vector<uint8_t> &isbool;
     const std::vector<Mono> &mono;
+    const std::vector<Ival> &range;                 // static interval of every node over the whole domain
+    const uint8_t dep_bit, var_leaf;
     std::unordered_map<uint64_t, int32_t> sub_memo;
-    std::unordered_map<int32_t, std::pair<int32_t, int32_t>> memo;   // node -> (ub, lb)
+    std::unordered_map<int32_t, B> memo;
+    struct IV { int32_t lo, hi; bool ok() const { return lo >= 0; } };
+    std::unordered_map<int32_t, IV> iv_memo;
     int32_t c_true, c_false, x0, xmax;
 
-    RowBounds(Dag &g_, const std::vector<uint8_t> &b, const std::vector<Mono> &m) : g(g_), isbool(b), mono(m) {
-        c_true = g.konst(1.0); c_false = g.konst(0.0); x0 = g.leaf(D_XMIN); xmax = g.leaf(D_XMAX);
+    RowBounds(Dag &g_, const std::vector<uint8_t> &b, const std::vector<Mono> &m, const std::vector<Ival> &rg, uint8_t dep_bit_, uint8_t var_leaf_,
+              uint8_t lo_leaf, uint8_t hi_leaf)
+        : g(g_), isbool(b), mono(m), range(rg), dep_bit(dep_bit_), var_leaf(var_leaf_) {
+        c_true = g.konst(1.0); c_false = g.konst(0.0); x0 = g.leaf(lo_leaf); xmax = g.leaf(hi_leaf);
     }
-    int32_t subst(int32_t i, int32_t xr) {          // i with X replaced by node xr
+    int32_t subst(int32_t i, int32_t xr) {          // i with the coordinate replaced by node xr
         const DNode d = g.n[i];
-        if (!(d.dep & DEP_X)) return i;
-        if (d.op == D_X) return xr;
+        if (!(d.dep & dep_bit)) return i;
+        if (d.op == var_leaf) return xr;
         const uint64_t key = ((uint64_t)(uint32_t)i << 32) | (uint32_t)xr;
         auto it = sub_memo.find(key);
         if (it != sub_memo.end()) return it->second;
@@ -360,29 +369,98 @@ struct RowBounds {
         return r;
     }
     int32_t b_not(int32_t a) { return g.binary(MARAY_OP_ADD, c_true, g.unary(MARAY_OP_NEG, a)); }
-    std::pair<int32_t, int32_t> bounds(int32_t i) {
-        if ((size_t)i >= isbool.size() || !isbool[i]) return {c_true, c_false};
+
+    // Interval of an arithmetic value over the span, as two expressions free of the coordinate: lo <= v <= hi for every
+    // value of the coordinate in [x0, xmax].  Every op here is correctly rounded, hence monotone in each operand, so
+    // interval arithmetic in the SAME arithmetic bounds the ROUNDED results (fl(a+b) <= fl(ha+hb) when a <= ha, b <= hb).
+    // Monotone sub-trees take their end points (tight); a difference of two increasing terms -- an edge function
+    // written as p - q -- gets [p(lo) - q(hi), p(hi) - q(lo)], which the end-point rule cannot bound at all.
+    // Only nodes that the static analysis proves NaN-free are bounded; sin / exp / ln / App are not.
+    IV ival(int32_t i) {
         const DNode d = g.n[i];
-        if (!(d.dep & DEP_X)) return {i, i};
+        if (!(d.dep & dep_bit)) return {i, i};
+        if (d.op == var_leaf) return {x0, xmax};
+        auto it = iv_memo.find(i);
+        if (it != iv_memo.end()) return it->second;
+        IV r{-1, -1};
+        const Mono m = (size_t)i < mono.size() ? mono[i] : M_NONE;
+        const bool clean = (size_t)i < range.size() && !range[i].nan;
+        if (m == M_INC) r = {subst(i, x0), subst(i, xmax)};
+        else if (m == M_DEC) r = {subst(i, xmax), subst(i, x0)};
+        else if (clean) {
+            auto rng = [&](int32_t k) { return (size_t)k < range.size() ? range[k] : Ival{-INFINITY, INFINITY, true}; };
+            switch (d.op) {
+            case MARAY_OP_MOV: r = ival(d.a); break;
+            case MARAY_OP_NEG: { const IV a = ival(d.a); if (a.ok()) r = {g.unary(MARAY_OP_NEG, a.hi), g.unary(MARAY_OP_NEG, a.lo)}; break; }
+            case MARAY_OP_STEP: { const IV a = ival(d.a); if (a.ok()) r = {g.unary(MARAY_OP_STEP, a.lo), g.unary(MARAY_OP_STEP, a.hi)}; break; }
+            case MARAY_OP_SQRT: { const IV a = ival(d.a); if (a.ok() && rng(d.a).lo >= 0) r = {g.unary(MARAY_OP_SQRT, a.lo), g.unary(MARAY_OP_SQRT, a.hi)}; break; }
+            case MARAY_OP_RECIP: {      // decreasing on either side of 0
+                const IV a = ival(d.a);
+                if (a.ok() && (rng(d.a).lo > 0 || rng(d.a).hi < 0)) r = {g.unary(MARAY_OP_RECIP, a.hi), g.unary(MARAY_OP_RECIP, a.lo)};
+                break;
+            }
+            case MARAY_OP_ABS: {
+                const IV a = ival(d.a);
+                if (!a.ok()) break;
+                if (rng(d.a).lo >= 0) r = a;
+                else if (rng(d.a).hi <= 0) r = {g.unary(MARAY_OP_NEG, a.hi), g.unary(MARAY_OP_NEG, a.lo)};
+                else r = {c_false /* +0.0 */, g.binary(MARAY_OP_MAX, g.unary(MARAY_OP_ABS, a.lo), g.unary(MARAY_OP_ABS, a.hi))};
+                break;
+            }
+            case MARAY_OP_ADD: case MARAY_OP_MIN: case MARAY_OP_MAX: {
+                const IV a = ival(d.a), b = ival(d.b);
+                if (a.ok() && b.ok()) r = {g.binary(d.op, a.lo, b.lo), g.binary(d.op, a.hi, b.hi)};
+                break;
+            }
+            case MARAY_OP_MUL: {
+                const IV a = ival(d.a), b = ival(d.b);
+                if (!a.ok() || !b.ok()) break;
+                const Ival ra = rng(d.a), rb = rng(d.b);
+                auto mul = [&](int32_t p, int32_t q) { return g.binary(MARAY_OP_MUL, p, q); };
+                if (ra.lo >= 0 && rb.lo >= 0) r = {mul(a.lo, b.lo), mul(a.hi, b.hi)};
+                else if (ra.hi <= 0 && rb.hi <= 0) r = {mul(a.hi, b.hi), mul(a.lo, b.lo)};
+                else if (ra.lo >= 0 && rb.hi <= 0) r = {mul(a.hi, b.lo), mul(a.lo, b.hi)};
+                else if (ra.hi <= 0 && rb.lo >= 0) r = {mul(a.lo, b.hi), mul(a.hi, b.lo)};
+                else {      // a sign is unknown: the extremes are among the four corner products
+                    const int32_t p0 = mul(a.lo, b.lo), p1 = mul(a.lo, b.hi), p2 = mul(a.hi, b.lo), p3 = mul(a.hi, b.hi);
+                    r = {g.binary(MARAY_OP_MIN, g.binary(MARAY_OP_MIN, p0, p1), g.binary(MARAY_OP_MIN, p2, p3)),
+                         g.binary(MARAY_OP_MAX, g.binary(MARAY_OP_MAX, p0, p1), g.binary(MARAY_OP_MAX, p2, p3))};
+                }
+                break;
+            }
+            default: break;
+            }
+        }
+        iv_memo.emplace(i, r);
+        return r;
+    }
+
+    B bounds(int32_t i) {
+        if ((size_t)i >= isbool.size() || !isbool[i]) return {c_true, c_false, true};
+        const DNode d = g.n[i];
+        if (!(d.dep & dep_bit)) return {i, i, false};
         auto it = memo.find(i);
         if (it != memo.end()) return it->second;
-        std::pair<int32_t, int32_t> r{c_true, c_false};
-        const Mono m = mono[i];
+        B r{c_true, c_false, true};
+        const Mono m = (size_t)i < mono.size() ? mono[i] : M_NONE;
         if (m == M_INC || m == M_DEC || m == M_MONO) {
             const int32_t at0 = subst(i, x0), atw = subst(i, xmax);
-            if (m == M_INC) r = {atw, at0};
-            else if (m == M_DEC) r = {at0, atw};
-            else r = {g.binary(MARAY_OP_MAX, at0, atw), g.binary(MARAY_OP_MIN, at0, atw)};
+            if (m == M_INC) r = {atw, at0, false};
+            else if (m == M_DEC) r = {at0, atw, false};
+            else r = {g.binary(MARAY_OP_MAX, at0, atw), g.binary(MARAY_OP_MIN, at0, atw), false};
         } else if (d.op == MARAY_OP_MUL || d.op == MARAY_OP_MIN) {
-            auto a = bounds(d.a), b = bounds(d.b);
-            r = {g.binary(MARAY_OP_MIN, a.first, b.first), g.binary(MARAY_OP_MIN, a.second, b.second)};
+            const B a = bounds(d.a), b = bounds(d.b);
+            r = {g.binary(MARAY_OP_MIN, a.ub, b.ub), g.binary(MARAY_OP_MIN, a.lb, b.lb), a.lossy || b.lossy};
         } else if (d.op == MARAY_OP_MAX) {
-            auto a = bounds(d.a), b = bounds(d.b);
-            r = {g.binary(MARAY_OP_MAX, a.first, b.first), g.binary(MARAY_OP_MAX, a.second, b.second)};
+            const B a = bounds(d.a), b = bounds(d.b);
+            r = {g.binary(MARAY_OP_MAX, a.ub, b.ub), g.binary(MARAY_OP_MAX, a.lb, b.lb), a.lossy || b.lossy};
         } else if (d.op == MARAY_OP_ADD) {       // 1 + -(b) = NOT b
             const int32_t nb = g.n[d.a].op == MARAY_OP_NEG ? d.a : d.b;
-            auto a = bounds(g.n[nb].a);
-            r = {b_not(a.second), b_not(a.first)};
+            const B a = bounds(g.n[nb].a);
+            r = {b_not(a.lb), b_not(a.ub), a.lossy};
+        } else if (d.op == MARAY_OP_STEP) {      // not monotone as a whole: bound its argument by interval arithmetic
+            const IV a = ival(d.a);
+            if (a.ok()) r = {g.unary(MARAY_OP_STEP, a.hi), g.unary(MARAY_OP_STEP, a.lo), false};
         }
         memo.emplace(i, r);
         return r;
@@ -805,6 +883,8 @@ struct Lowerer {
             if (d.op == D_Y) return MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_Y);
             if (d.op == D_XMAX) return MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_XMAX);
             if (d.op == D_XMIN) return MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_XMIN);
+            if (d.op == D_YMAX) return MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_YMAX);
+            if (d.op == D_YMIN) return MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_YMIN);
             if (in_section[c]) {
                 if (acc_holder[j] == c) { sec.acc_operands++; return MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_ACC); }
                 if (slot[c] < 0) throw Error{MARAY_E_INTERNAL, "operand without a slot"};
@@ -900,7 +980,7 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         const std::vector<uint8_t> isb0 = bool_typing();
         const std::vector<Ival> iv0 = intervals(g);
         const std::vector<Mono> mono0 = monotonicity(g, iv0);
-        RowBounds rb(g, isb0, mono0);
+        RowBounds rb(g, isb0, mono0, iv0, DEP_X, D_X, D_XMIN, D_XMAX);
         rowub.assign(N0, -1);
         std::vector<uint32_t> shapes(N0, 1);          // operands of the OR tree below a node
         for (size_t i = 0; i < N0; i++) {
@@ -912,8 +992,22 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
             const bool conj = op == MARAY_OP_MUL || op == MARAY_OP_MIN;
             const bool group = op == MARAY_OP_MAX && ((shapes[i] >= 3 && shapes[i] <= 4) || (shapes[i] >= 9 && shapes[i] <= 16));
             if (!conj && !group) continue;
-            const int32_t ub = rb.bounds((int32_t)i).first;
+            const int32_t ub = rb.bounds((int32_t)i).ub;
             if (g.n[ub].op < D_CONST) rowub[i] = ub;          // a real y-only op (not folded to a constant)
+        }
+        // Second pass, over y: a guard that is built from booleans monotone in y as well is bounded over the rows
+        // [YMIN, YMAX] the same way, and then holds for a rectangle of pixels -- an evaluator may compute it once for
+        // several rows.  A guard that is not keeps reading Y: exact for its row, valid for that row only.
+        if (opts.no_y_spans == 0) {
+            const std::vector<uint8_t> isb1 = bool_typing();
+            const std::vector<Ival> iv1 = intervals(g);
+            const std::vector<Mono> mono_y = monotonicity(g, iv1, DEP_Y, D_Y);
+            RowBounds rby(g, isb1, mono_y, iv1, DEP_Y, D_Y, D_YMIN, D_YMAX);
+            for (size_t i = 0; i < N0; i++) {
+                if (rowub[i] < 0) continue;
+                const RowBounds::B u = rby.bounds(rowub[i]);
+                if (!u.lossy && g.n[u.ub].op < D_CONST) rowub[i] = u.ub;
+            }
         }
         rowub.resize(g.n.size(), -1);
     }

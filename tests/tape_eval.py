@@ -59,7 +59,7 @@ def _cast_u32(v):
     return np.minimum(v, 4294967295.0).astype(np.uint64)
 
 
-def run_section(ops, consts, n_slots, X, Y, yvals, textures, n_out, honor_skips=False, w=None, span=None):
+def run_section(ops, consts, n_slots, X, Y, yvals, textures, n_out, honor_skips=False, w=None, span=None, yspan=None):
     """Evaluate one section for a vector of items.  X, Y: float64 arrays (same
     shape); yvals: array [..., n_yvals] broadcastable per item or None.
     honor_skips: take SKIPZ / SKIPNZ when the whole vector agrees (call per 64-item "wavefront")."""
@@ -75,6 +75,8 @@ def run_section(ops, consts, n_slots, X, Y, yvals, textures, n_out, honor_skips=
         if kind == K_YVAL: return yvals[..., idx]
         if idx == 3: return np.full(shape, float(span[1] if span else w - 1))      # XMAX
         if idx == 4: return np.full(shape, float(span[0] if span else 0))          # XMIN
+        if idx == 5: return Y if yspan is None else np.broadcast_to(yspan[1], shape)     # YMAX (per row: = Y)
+        if idx == 6: return Y if yspan is None else np.broadcast_to(yspan[0], shape)     # YMIN
         return X if idx == 0 else (Y if idx == 1 else acc)
 
     with np.errstate(all='ignore'):
@@ -128,11 +130,13 @@ def run_section(ops, consts, n_slots, X, Y, yvals, textures, n_out, honor_skips=
     return outs
 
 
-def render_rows_waves(tape, w, y0, y1, textures=None, tile=None):
+def render_rows_waves(tape, w, y0, y1, textures=None, tile=None, yrows=None):
     """Like render_rows, but wavefront by wavefront (64 consecutive x of one row; the ROW section in
     groups of 64 rows) with SKIPZ / SKIPNZ honoured the way the device kernels do.  tile: evaluate
     the ROW section once per `tile` pixels of a row with XMIN / XMAX = that span (what the
-    specialised kernels do for the guard values) instead of once per row."""
+    specialised kernels do for the guard values) instead of once per row.  yrows: additionally
+    with YMIN / YMAX = the ends of the group of `yrows` rows a row belongs to (legal only for a
+    tape none of whose guards reads Y; the caller checks)."""
     consts, row_ops, pix_ops = tape.arrays()
     info = tape.info
     rows = y1 - y0
@@ -145,7 +149,12 @@ def render_rows_waves(tape, w, y0, y1, textures=None, tile=None):
             yv_all = np.zeros((rows, info['n_yvals']))
             for r0 in range(0, rows, 64):
                 ys = np.arange(y0 + r0, min(y1, y0 + r0 + 64), dtype=np.float64)
-                outs = run_section(row_ops, consts, info['n_row_slots'], None, ys, None, textures, info['n_yvals'], True, w=w, span=span)
+                ysp = None
+                if yrows:
+                    lo = y0 + ((ys - y0) // yrows) * yrows
+                    ysp = (lo, np.minimum(lo + yrows - 1, y1 - 1))
+                outs = run_section(row_ops, consts, info['n_row_slots'], None, ys, None, textures, info['n_yvals'], True, w=w, span=span,
+                                   yspan=ysp)
                 yv_all[r0:r0 + len(ys)] = np.stack(outs, axis=-1)
         yv_span.append(yv_all)
     for r in range(rows):
@@ -181,3 +190,44 @@ def cast_u8(v):
     """Rust `as u8`."""
     v = np.where(v > 0, v, 0.0)
     return np.minimum(v, 255.0).astype(np.uint8)
+
+
+def guards_reading_y(tape):
+    """How many guards (y values that only gate SKIP ops of the PIXEL section) have SPEC Y in their cone: those are
+    exact for one row and must be evaluated per row; a tape with none may have its guards evaluated for groups of rows
+    (YMIN / YMAX).  Returns (n_guards, n_reading_y)."""
+    consts, row_ops, pix_ops = tape.arrays()
+    used_as_operand, used_as_guard = set(), set()
+    for ins in pix_ops:
+        op, aux, dst, ra, rb = decode(ins)
+        if op == OP['NOP']:
+            continue
+        if ra >> 14 == K_YVAL:
+            (used_as_guard if op in (OP['SKIPZ'], OP['SKIPNZ']) else used_as_operand).add(ra & 0x3FFF)
+        if OP['ADD'] <= op <= OP['APP'] and rb >> 14 == K_YVAL:
+            used_as_operand.add(rb & 0x3FFF)
+    guards = used_as_guard - used_as_operand
+    reads_y, slot_writer, acc = {}, {}, None
+    n_reading = 0
+
+    def src(ref):
+        kind, idx = ref >> 14, ref & 0x3FFF
+        if kind == K_SLOT: return reads_y.get(slot_writer.get(idx), False)
+        if kind == K_SPEC: return idx == 1 or (idx == 2 and reads_y.get(acc, False))
+        return False
+    for j, ins in enumerate(row_ops):
+        op, aux, dst, ra, rb = decode(ins)
+        if op in (OP['NOP'], OP['SKIPZ'], OP['SKIPNZ']):
+            continue
+        r = src(ra) if op != OP['TEXDIM'] else False
+        if op == OP['OUT']:
+            if aux in guards and r:
+                n_reading += 1
+            continue
+        if OP['ADD'] <= op <= OP['APP']:
+            r = r or src(rb)
+        reads_y[j] = r
+        acc = j
+        if dst != DST_NONE:
+            slot_writer[dst] = j
+    return len(guards), n_reading

@@ -27,7 +27,7 @@ def lowered(seed, n_tex):
 
 def test_random_scenes_lowering_vs_oracle():
     tex = scenes.textures(scale=64)
-    done = 0
+    done = yspans = 0
     for seed in range(60):
         n_tex = 2 if seed % 3 == 0 else 0
         data, tape = lowered(seed, n_tex)
@@ -41,6 +41,9 @@ def test_random_scenes_lowering_vs_oracle():
         if tape.info['skip_ops']:
             assert same_f64(tape_eval.render_rows_waves(tape, W, 0, H, t), want64), seed
             assert same_f64(tape_eval.render_rows_waves(tape, W, 0, H, t, tile=64), want64), seed      # guards per span
+            if tape_eval.guards_reading_y(tape)[1] == 0:                                                # ... and per group of rows
+                assert same_f64(tape_eval.render_rows_waves(tape, W, 0, H, t, tile=64, yrows=4), want64), seed
+                yspans += 1
         done += 1
     assert done >= 50
 

@@ -56,13 +56,13 @@ def test_row_section_is_cut_into_chunks(chess_bytes):
     assert L.maray_jit_source_rows(C.byref(tape.program), C.byref(src), C.byref(k)) == 0, L.maray_last_error()
     text = C.string_at(src).decode()
     L.maray_free(src)
-    rows_src, guards_src = text.split('// guards: (row, tile)')
+    rows_src, guards_src = text.split('// guards: (row group, tile)')
     assert 2 <= k.value <= 16 and rows_src.count('    case ') == k.value
     written = sorted(int(m) for m in re.findall(r'yout\[(\d+)\] = ', rows_src))
     n_num = len(written)
     assert written == list(range(n_num)) and 0 < n_num < tape.info['n_yvals']
     n_guards = tape.info['n_yvals'] - n_num
     assert len(re.findall(r'gacc \|= ', guards_src)) == n_guards and 'yout[' not in guards_src.split('switch')[1]
-    assert guards_src.count('    case ') == (n_guards + 15) // 16       # 16 guards per job: many short wavefronts
+    assert guards_src.count('    case ') == (n_guards + 7) // 8        # 8 guards per job: many short wavefronts
     assert 'XMIN' in guards_src and 'XMIN' not in rows_src.split('switch')[1]      # only guards depend on the span
     build(tape)        # compiles the ROW kernel as well

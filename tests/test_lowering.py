@@ -144,6 +144,15 @@ def test_guards_bounded_over_a_tile_preserve_values(chess_bytes):
         assert same_f64(tape_eval.render_rows_waves(tape, 2048, y0, y0 + 1, tile=256), want64), y0
     _, want64 = o.render_rows(2048, 2048, 1408, 1409)
     assert same_f64(tape_eval.render_rows_waves(tape, 2048, 1408, 1409, tile=64), want64)      # any span of whole wavefronts
+    # ... and for groups of rows: every guard of chess is bounded over y as well (none reads Y), so one evaluation
+    # serves a rectangle of pixels
+    n_guards, n_read_y = tape_eval.guards_reading_y(tape)
+    assert n_guards == 168 and n_read_y == 0
+    for y0 in (696, 1400):
+        _, want64 = o.render_rows(2048, 2048, y0, y0 + 16)
+        assert same_f64(tape_eval.render_rows_waves(tape, 2048, y0, y0 + 16, tile=256, yrows=8), want64), y0
+    rowwise = s.lower(y_spans=False)
+    assert tape_eval.guards_reading_y(rowwise) == (168, 168) and rowwise.info['n_row_ops'] < tape.info['n_row_ops']
 
 
 def test_unfused_chess_tape_equals_oracle(chess_bytes):
