@@ -299,6 +299,7 @@ struct TapeBackend final : Backend {
                 const unsigned *tile_list = nullptr, const double *ext_yvals = nullptr) {
         const uint32_t rows = rb.n_rows, y0 = rb.y0;
         if (!rows || !w) return;
+        (void)hipGetLastError();        // the launches below are checked with hipGetLastError(): drop what an earlier, unrelated call left
         if (!ext_yvals) ensure(d_yvals, yvals_cap, (size_t)rows * std::max<uint32_t>(P.n_yvals, 1));
         if (ext_yvals) rows_pass = false;
         if (rows_pass && P.n_row_ops) {

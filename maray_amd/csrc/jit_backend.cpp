@@ -836,7 +836,7 @@ struct JitBackend final : Backend {
         unsigned blk_rows = rb.block_rows, blk_stride = rb.block_stride;
         if (!rows_total || !w) return;
         // rows per guard evaluation: a group must not straddle two row blocks (its image rows have to be consecutive)
-        unsigned yrows = (guard_rows > 1 && blk_rows % guard_rows == 0) ? guard_rows : 1u;
+        unsigned yrows = (guard_rows > 1 && (blk_rows >= rows_total || blk_rows % guard_rows == 0)) ? guard_rows : 1u;
         const uint32_t n_groups = (rows_total + yrows - 1) / yrows;
         ensure(d_yvals, yvals_cap, (size_t)rows_total * std::max<uint32_t>(P.n_yvals, 1));
         {

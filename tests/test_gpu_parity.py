@@ -291,3 +291,17 @@ def test_row_blocks_in_one_launch_equal_the_blocks_one_by_one():
     code = _BLOCKS_SCRIPT % dict(root=os.path.dirname(here), tests=here, scene=os.path.join(GOLDEN, 'chess.maray'))
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and 'blocks ok' in out.stdout, out.stderr[-3000:]
+
+
+def test_guards_per_group_of_rows_with_ragged_ranges(chess_bytes):
+    """The specialised path evaluates chess's guards once per 8 rows x 256 pixels; ranges that do not start or end on
+    a multiple of 8 have a partial group at the end.  Against the interpreter, which evaluates them row by row."""
+    tape = M.Scene(chess_bytes).lower()
+    jit = M.Context(tape, backend=M.BACKEND_JIT)
+    ref = M.Context(tape, backend=M.BACKEND_TAPE_SMEM)
+    for y0, y1 in ((5, 1021), (509, 516), (700, 713)):
+        a8, a64 = jit.render_rows(1024, 1024, y0, y1)
+        b8, b64 = ref.render_rows(1024, 1024, y0, y1)
+        assert np.array_equal(a8, b8) and same_f64(a64, b64), (y0, y1)
+    jit.close()
+    ref.close()
