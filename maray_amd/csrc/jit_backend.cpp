@@ -222,9 +222,7 @@ struct Emitter {
                 if (!declared) out += typed_bool ? "    mr_mask b" + std::string(name) + ";\n" : "    double " + std::string(name) + ";\n";
                 // regions are entered rarely (chess: 2-20 %): mark them unlikely so that the block placement keeps the
                 // skip path as the fall-through and moves the region bodies out of line (taken jumps stall on instruction fetch)
-                const bool cold = !getenv("MARAY_JIT_NO_EXPECT");
-                const std::string &test = cond;
-                out += cold ? "    if (__builtin_expect(" + test + ", 0)) {\n" : "    if (" + test + ") {\n";
+                out += "    if (__builtin_expect(" + cond + ", 0)) {\n";
                 open.push_back(Open{end, typed_bool, nz});
                 ktab_block.clear();
                 continue;
@@ -567,10 +565,10 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
     const int min_waves = env_waves ? atoi(env_waves) : min_waves_arg;
     const uint32_t n_ynum = numeric_yvals(P);   // y values read as operands (a prefix of the table); the rest only gate SKIPs
     const bool y_lds = n_ynum > 0 && n_ynum <= 4096 && !(env_ylds && env_ylds[0] == '0');
-    // Row-level SKIP ops (guard = a y value that bounds a boolean over a span of the row): maray_jit_guards has
-    // evaluated them for every 256-pixel tile and packed them 64 per word; the words of the tile at hand sit in SGPRs
-    // (one scalar load per trip of the tile loop) and a region's test is one s_bitcmp1_b64.  Without usable guard
-    // words (none, too many, or MARAY_JIT_ROW_GUARDS=0) those SKIP ops are compiled away.
+    // SKIP ops whose guard is a y value (a bound of a boolean over a span of pixels): maray_jit_rows has evaluated the
+    // guards for every rectangle of `yrows` rows x 256 pixels and packed them 64 per word; the block stages the words
+    // of all its tiles in LDS, the words of the tile at hand sit in SGPRs and a region's test is one s_bitcmp1_b64.
+    // Without usable guard words (none, too many, or MARAY_JIT_ROW_GUARDS=0) those SKIP ops are compiled away.
     const uint32_t n_gwords = jit_guard_words(P);
     E.ignore_row_guards = n_gwords == 0;
     if (n_gwords) { E.guard_first = n_ynum; E.guard_words = n_gwords; }
@@ -616,14 +614,17 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
     if (E.guard_words) s += "    if (threadIdx.x < " + std::to_string(16 * E.guard_words) + "u) mr_gq[threadIdx.x] = gs;\n";
     s += "    __syncthreads();\n"
          "    const double Y = (double)(y0 + ((row_base + r) / blk_rows) * blk_stride + (row_base + r) % blk_rows);     // -> image row (RowBlocks)\n"
-         "    mr_kptr yv = (mr_kptr)yrow;\n"
-         "    const __attribute__((address_space(4))) unsigned *yw = (const __attribute__((address_space(4))) unsigned *)yv;\n"
-         "    (void)Y; (void)yv; (void)yw; (void)tex; (void)gbits; (void)n_tx; (void)yrows;\n";
+         "    unsigned long long mr_ybase = (unsigned long long)yrow;\n"
+         "    (void)Y; (void)tex; (void)gbits; (void)n_tx; (void)yrows;\n";
     s += "    const unsigned mr_lane = threadIdx.x & 63u;                              // dword mr_lane of a wave's RGB8 run starts\n"
          "    const unsigned mr_src = (mr_lane * 4u) / 3u, mr_shift = ((mr_lane * 4u) % 3u) * 8u;   // in pixel mr_src, mr_shift bits in\n"
          "    for (unsigned t = 0; t < tiles; t++) {\n"
          "    const unsigned x0 = (blockIdx.x * tiles + t) * 256u;\n"
          "    if (x0 >= w) break;\n"
+         "    asm volatile(\"\" : \"+s\"(mr_ybase));          // y values read by scalar loads: not to be hoisted out of the loop either\n"
+         "    mr_kptr yv = (mr_kptr)mr_ybase;\n"
+         "    const __attribute__((address_space(4))) unsigned *yw = (const __attribute__((address_space(4))) unsigned *)yv;\n"
+         "    (void)yv; (void)yw;\n"
          "/*MR_KBASE*/";
     if (E.guard_words) {
         for (uint32_t j = 0; j < E.guard_words; j++)
@@ -785,8 +786,8 @@ struct JitBackend final : Backend {
         std::vector<char> code, code_rows;
         std::string log;
         // Occupancy: the highest of 8 / 6 / 4 waves per SIMD (<= 64 / 80 / 128 VGPRs) whose build needs no scratch:
-        // spilled VGPRs are HBM traffic (chess @4096^2 at 8 waves: 44 B per work-item = 0.6 GB per launch for 4 %
-        // more speed; MARAY_JIT_WAVES=8 asks for that build).
+        // spilled VGPRs are HBM traffic.  (chess needs 36-40 VGPRs since its row regions are private: the first build
+        // is taken.  MARAY_JIT_WAVES=<n> forces a build for n waves.)
         const int ladder[] = {8, 6, 4};
         for (int k = 0; k < 3; k++) {
             if (mod) { (void)hipModuleUnload(mod); mod = nullptr; }
