@@ -5,7 +5,7 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 is launched under torch.distributed.run with one rank per GPU.  A "step" is one
 pass of the hot path over the rank's share (4096 x 4096 pixels) of one image of
 the chess scene, outputs resident in HBM.  Pixels are independent, so ranks own
-disjoint rows (interleaved 256-row blocks, for balance) and no data-path
+disjoint rows (interleaved 64-row blocks, for balance) and no data-path
 collective is issued (weak scaling: pixels per GPU are fixed); the only
 collectives are the timing barrier and the max-over-ranks of the elapsed time.
 
@@ -35,6 +35,7 @@ PEAK_F64_TOPS = 39.3               # MI355X f64 VALU, non-FMA instr/s: 256 CU x 
 PEAK_HBM_GBS = 8000.0
 W = 4096
 H_TILE = 4096
+BLOCK_ROWS = 64                    # rows are dealt to the ranks in blocks of this many (a multiple of the 8-row guard groups)
 
 
 def main():
@@ -69,14 +70,14 @@ def main():
     scene = M.Scene(data)
     # N = 1: config 3, chess.maray regenerated at 4096 x 4096 (exact power-of-two rescale).  N > 1: the same scene
     # at N x 4096^2 pixels (8192x4096, 8192^2, 16384x8192 = config 4's width), rows dealt to the ranks in interleaved
-    # 256-row blocks so that every rank sees sky and board alike: equal pixels per rank, no data-path collective.
+    # 64-row blocks so that every rank sees sky and board alike: equal pixels per rank, no data-path collective.
     from maray_amd.sharding import interleaved_blocks, interleaved_layout, max_over_ranks, scene_scale
     sx, sy = scene_scale(n_gpus)
     scene.rescale(sx, sy)
     w_img, h_total = scene.size
     tape = scene.lower(row_guards=os.environ.get('MARAY_BENCH_ROW_GUARDS', '1') != '0')
-    blocks = interleaved_blocks(rank, n_gpus, h_total, 256)
-    layout = interleaved_layout(rank, n_gpus, h_total, 256)     # the same rows as one launch (None: ragged, block by block)
+    blocks = interleaved_blocks(rank, n_gpus, h_total, BLOCK_ROWS)
+    layout = interleaved_layout(rank, n_gpus, h_total, BLOCK_ROWS)     # the same rows as one launch (None: ragged, block by block)
     rows_mine = sum(b - a for a, b in blocks)
 
     backends = {'tape': M.BACKEND_TAPE, 'tape-smem': M.BACKEND_TAPE_SMEM, 'jit': M.BACKEND_JIT}
@@ -204,7 +205,7 @@ def main():
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'data/chess.maray rescaled to %d x %d (SURVEY.md §8(d) config 3 at N=1; N x 4096^2 pixels '
-                                   'of the same scene at N>1), rows dealt to the ranks in interleaved 256-row blocks'
+                                   'of the same scene at N>1), rows dealt to the ranks in interleaved 64-row blocks'
                                    % (w_img, h_total),
                        'backend': backend_name, 'kernel': ctx.kernel_name, 'pixels_per_step': px_per_step,
                        'tape_ops_per_pixel': tape.info['n_pix_ops'], 'parallelism': 'row tiles, no collective',

@@ -862,9 +862,10 @@ struct JitBackend final : Backend {
         }
         const unsigned n_tx = (w + 255) / 256;
         const uint64_t n_tiles = (uint64_t)n_tx * rows_total;
-        // tiles per block: amortise the per-block prologue while leaving >= 16 blocks per CU to balance the tail
-        // (chess @4096^2, tiles = 1 / 2 / 4 / 8 / 16: 0.385 / 0.366 / 0.353 / 0.354 / 0.340 ms)
-        unsigned tiles = has_sin ? 1u : (unsigned)std::min<uint64_t>(std::min<uint64_t>(16, n_tx), std::max<uint64_t>(1, n_tiles / 4096));
+        // tiles per block: amortise the per-block prologue, but rows cost what they show (sky: nothing, board: 5x the
+        // average) and blocks are the unit of load balance (chess @4096^2, tiles = 2 / 4 / 8 / 16: 68 / 59 / 52 / 58 us;
+        // walking the rows in a scattered order to mix cheap and dear ones costs more in cache locality than it balances)
+        unsigned tiles = has_sin ? 1u : (unsigned)std::min<uint64_t>(std::min<uint64_t>(8, n_tx), std::max<uint64_t>(1, n_tiles / 4096));
         if (const char *e_ = getenv("MARAY_JIT_TILES")) if (!has_sin && atoi(e_) > 0) tiles = (unsigned)std::min(16, atoi(e_));      // tuning knob (the kernel stages guard words for <= 16 tiles)
         const unsigned gx = (n_tx + tiles - 1) / tiles;
         if (n_tiles > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
