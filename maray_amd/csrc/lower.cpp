@@ -230,6 +230,10 @@ Ival ival_mul(const Ival &a, const Ival &b)
         if (p != p) { r.nan = true; r.lo = -INFINITY; r.hi = INFINITY; continue; }   // 0 * inf
         r.lo = std::min(r.lo, p); r.hi = std::max(r.hi, p);
     }
+    // 0 * inf in the interior: one factor can be zero while the other can be infinite
+    const bool a_zero = a.lo <= 0 && a.hi >= 0, b_zero = b.lo <= 0 && b.hi >= 0;
+    const bool a_inf = std::isinf(a.lo) || std::isinf(a.hi), b_inf = std::isinf(b.lo) || std::isinf(b.hi);
+    if ((a_zero && b_inf) || (b_zero && a_inf)) { r.nan = true; r.lo = -INFINITY; r.hi = INFINITY; }
     r.lo = down(r.lo); r.hi = up(r.hi);
     return r;
 }

@@ -62,3 +62,21 @@ def textured(w):
             e = mul(e, div(app(image_width(1), x(), y()), app(image_width(1), nat(0), nat(0))))
         out.append(e)
     return out
+
+
+def shapes_through_inf_and_nan():
+    """Guarded shapes whose factors pass through inf and NaN inside a 192 x 24 image: 1/(x-40) (a pole), exp of a large
+    argument (overflow from x = 118), 0 * inf and inf - inf (NaN; step(NaN) = 0), next to honest linear edges."""
+    from marayb import add, exp, max_, min_, mul, nat, recip, sin, step, sub, x, y
+    pole = recip(sub(x(), nat(40)))
+    blow = exp(mul(sub(x(), nat(100)), nat(40)))
+    f1 = step(add(mul(pole, sub(y(), nat(7))), nat(1)))
+    f2 = step(sub(blow, mul(blow, nat(2))))
+    f3 = step(sub(nat(150), add(x(), mul(y(), nat(2)))))
+    f4 = step(sub(add(mul(x(), nat(3)), y()), nat(60)))
+    heavy = step(sin(mul(add(mul(x(), x()), mul(y(), nat(3))), recip(nat(7)))))
+    for k in range(5):
+        heavy = min_(heavy, step(add(mul(x(), nat(k + 1)), sub(nat(400 * (k + 1)), mul(y(), nat(9))))))
+    shape_a = mul(mul(mul(f3, f4), f1), heavy)
+    shape_b = mul(mul(f3, max_(f2, f4)), mul(heavy, step(sub(y(), nat(3)))))
+    return [mul(max_(shape_a, shape_b), nat(255)), mul(shape_a, add(x(), nat(1))), add(shape_b, mul(f1, nat(2)))]

@@ -322,3 +322,9 @@ def test_specialised_kernel_variants_selected_by_tuning_knobs(chess_bytes, monke
         for k in env:
             monkeypatch.delenv(k)
         assert hashlib.sha256(got8.tobytes()).hexdigest() == g['rgb8_sha256'], env
+
+
+def test_guarded_shapes_through_inf_and_nan():
+    """The scene of tests/test_lowering.py's soundness test on the device, all three evaluators, ragged width."""
+    gpu_vs_oracle(encode((192, 24), scenes.shapes_through_inf_and_nan()), 192, 24, [(0, 24)])
+    gpu_vs_oracle(encode((700, 40), scenes.shapes_through_inf_and_nan()), 700, 40, [(0, 40), (3, 29)])

@@ -218,3 +218,20 @@ def test_app_range_is_checked_at_context_creation():
     with pytest.raises(M.MarayError) as e:
         M.Context(t, textures=None)
     assert e.value.code in (-6,)
+
+
+def test_guards_stay_sound_where_values_overflow_or_turn_nan():
+    """Shapes whose factors pass through inf and NaN inside the image (1/(x-40), exp of a large argument, 0 * inf,
+    inf - inf): the static range analysis must refuse to bound those factors, and what the guards then say must
+    still never hide a pixel -- per row, per tile, per rectangle."""
+    w, h = 192, 24
+    data = encode((w, h), scenes.shapes_through_inf_and_nan())
+    tape = M.Scene(data).lower()
+    n_guards, n_read_y = tape_eval.guards_reading_y(tape)
+    assert n_guards >= 1
+    _, want64 = OScene(data).render_rows(w, h, 0, h)
+    assert same_f64(tape_eval.render_rows(tape, w, 0, h), want64)
+    assert same_f64(tape_eval.render_rows_waves(tape, w, 0, h), want64)
+    assert same_f64(tape_eval.render_rows_waves(tape, w, 0, h, tile=64), want64)
+    if n_read_y == 0:
+        assert same_f64(tape_eval.render_rows_waves(tape, w, 0, h, tile=64, yrows=8), want64)
