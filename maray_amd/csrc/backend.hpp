@@ -1,6 +1,7 @@
 // backend.hpp — device evaluator interface behind the tape-level ABI (product code).
 #pragma once
 
+#include <array>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -43,6 +44,23 @@ std::string jit_source(const maray_program &prog, int min_waves = 8);   // PIXEL
 std::string jit_source_rows(const maray_program &prog, uint32_t *n_chunks_out = nullptr, uint32_t *n_gjobs_out = nullptr);   // ROW kernel source (blockIdx.y = chunk)
 void jit_compile(const std::string &src, std::vector<char> &code, std::string &log);     // hiprtc, gfx950; throws Error
 void validate_program(const maray_program &p);
+
+// ---- ROW-tape analysis shared by the evaluators (row_split.cpp) ------------------------------------
+// Number of leading y values that PIXEL ops read as arithmetic operands; the rest of the table only gates SKIP ops.
+uint32_t numeric_yvals(const maray_program &P);
+struct RowTapeDeps {
+    std::vector<std::array<int32_t, 2>> deps;   // per op: the ops that produce its operands (-1: none)
+    std::vector<uint32_t> outs;                 // OUT ops, tape order
+    std::vector<uint8_t> reads_y;               // per op: SPEC Y is somewhere in its cone
+};
+RowTapeDeps row_tape_deps(const maray_program &P);
+// The ROW tape with everything but the cone of the given OUT ops turned into NOPs (SKIP regions kept when their end is).
+std::vector<uint64_t> row_tape_cone(const maray_program &P, const RowTapeDeps &d, const std::vector<uint32_t> &outs, size_t *cost);
+// The same tape without its NOPs (SKIP op counts adjusted).
+std::vector<uint64_t> compact_tape(const std::vector<uint64_t> &tape);
+// Does any guard (a y value that only gates SKIP ops) have SPEC Y in its cone?  If none does, guards may be evaluated
+// once for a group of rows (YMIN / YMAX, include/maray_tape.h).
+bool any_guard_reads_y(const maray_program &P);
 
 }   // namespace maray
 

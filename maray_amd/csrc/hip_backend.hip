@@ -49,6 +49,12 @@ struct KArgs {
     uint32_t w, y0, rows;      // image width, first row, row count of this launch
     uint32_t blk_rows, blk_stride;   // launch row r is image row y0 + (r / blk_rows) * blk_stride + r % blk_rows (RowBlocks)
     uint32_t tiles_per_row, n_tiles;
+    // Guards evaluated per rectangle of guard_rows rows x 256 pixels (guard_w32 != 0): bit g of a rectangle's words =
+    // guard guard_first + g.  PIXEL reads them instead of y values; the GUARDS kernel (job j = 8 guards = one byte,
+    // tape[job_off[j] .. + job_len[j])) writes them.
+    uint32_t *gbits;
+    const uint32_t *job_off, *job_len;
+    uint32_t guard_first, guard_w32, guard_rows;
 };
 
 typedef const __attribute__((address_space(4))) uint64_t *k_u64_ptr;   // constant address space: scalar loads
@@ -56,33 +62,58 @@ typedef const __attribute__((address_space(4))) double *k_f64_ptr;
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+enum { MODE_PIXEL = 0, MODE_ROW = 1, MODE_GUARDS = 2 };
+
+// What one work-item evaluates the tape for.
+struct Item {
+    const double *yrow;            // PIXEL: the row's y values
+    const uint32_t *gk;            // PIXEL: the guard words of the pixel's rectangle, or null (guards are y values)
+    double X, Y;                   // pixel / row coordinates
+    double xmin, xmax, ymin, ymax; // ROW sections: the span of pixels the guards are bounded over
+    double *yout;                  // MODE_ROW: OUT k -> yout[k]
+};
+
 // One pass over a tape section for the calling work-item.
-//   ROW = false: item is a pixel, OUT k -> out[k] (k = 0,1,2)
-//   ROW = true : item is an image row, OUT k -> yout[k]
-template <bool TAPE_LDS, bool ROW>
-__device__ __forceinline__ void run_tape(const KArgs &A, const uint64_t *tape_lds, const double *consts_lds,
+//   MODE_PIXEL : item is a pixel, OUT k -> out[k] (k = 0,1,2)
+//   MODE_ROW   : item is an image row, OUT k -> yout[k]
+//   MODE_GUARDS: item is a rectangle of pixels, OUT k (a guard) -> bit (k - guard_first) % 8 of `gacc`
+template <bool TAPE_LDS, int MODE>
+__device__ __forceinline__ void run_tape(const KArgs &A, const uint64_t *tape_g, uint32_t n_ops, const uint64_t *tape_lds, const double *consts_lds,
                                          double *slots, double *spill_base, uint32_t spill_stride,
-                                         const double *yrow, double X, double Y, double *yout,
-                                         double &o0, double &o1, double &o2)
+                                         const Item &I, double &o0, double &o1, double &o2, uint32_t &gacc)
 {
     const uint32_t tid = threadIdx.x;
     const uint32_t n_lds = A.n_lds_slots;
+    const double X = I.X, Y = I.Y;
     double acc = 0.0;
-    k_u64_ptr tape_k = (k_u64_ptr)A.tape;
+    k_u64_ptr tape_k = (k_u64_ptr)tape_g;
     k_f64_ptr consts_k = (k_f64_ptr)A.consts;
-    k_f64_ptr yrow_k = (k_f64_ptr)yrow;
+    k_f64_ptr yrow_k = (k_f64_ptr)I.yrow;
+    const __attribute__((address_space(4))) uint32_t *gk_k = (const __attribute__((address_space(4))) uint32_t *)I.gk;
 
     auto fetch = [&](uint32_t ref) -> double {
         const uint32_t kind = ref >> 14, idx = ref & 0x3FFFu;   // wave-uniform
         if (kind == MARAY_K_SLOT) return idx < n_lds ? slots[idx * BLOCK + tid] : spill_base[(size_t)(idx - n_lds) * spill_stride];
         if (kind == MARAY_K_CONST) return TAPE_LDS ? consts_lds[idx] : consts_k[idx];
-        if (kind == MARAY_K_YVAL) return yrow_k[idx];
-        // guards are evaluated once per row here: the span is the whole row, XMIN = 0 and XMAX = w - 1
-        if (idx == MARAY_SPEC_YMAX || idx == MARAY_SPEC_YMIN) return Y;     // ... and one row at a time
-        return idx == MARAY_SPEC_X ? X : (idx == MARAY_SPEC_Y ? Y : (idx == MARAY_SPEC_ACC ? acc : (idx == MARAY_SPEC_XMAX ? (double)(A.w - 1u) : 0.0)));
+        if (kind == MARAY_K_YVAL) {
+            if (MODE == MODE_PIXEL && I.gk && idx >= A.guard_first) {      // a guard of this pixel's rectangle: one bit
+                const uint32_t g = idx - A.guard_first;
+                return ((gk_k[g >> 5] >> (g & 31u)) & 1u) ? 1.0 : 0.0;
+            }
+            return yrow_k[idx];
+        }
+        switch (idx) {
+        case MARAY_SPEC_X: return X;
+        case MARAY_SPEC_Y: return Y;
+        case MARAY_SPEC_ACC: return acc;
+        case MARAY_SPEC_XMAX: return I.xmax;
+        case MARAY_SPEC_XMIN: return I.xmin;
+        case MARAY_SPEC_YMAX: return I.ymax;
+        default: return I.ymin;
+        }
     };
 
-    for (uint32_t pc = 0; pc < A.n_ops; ++pc) {
+    for (uint32_t pc = 0; pc < n_ops; ++pc) {
         uint32_t lo, hi;
         if (TAPE_LDS) {
             const uint64_t ins = tape_lds[pc];           // same LDS address in every lane: broadcast read
@@ -129,7 +160,8 @@ __device__ __forceinline__ void run_tape(const KArgs &A, const uint64_t *tape_ld
         }
         case MARAY_OP_OUT: {
             const double v = fetch(ra);
-            if (ROW) yout[aux] = v;
+            if (MODE == MODE_ROW) I.yout[aux] = v;
+            else if (MODE == MODE_GUARDS) { if (v != 0.0) gacc |= 1u << ((aux - A.guard_first) & 7u); }
             else if (aux == 0) o0 = v;
             else if (aux == 1) o1 = v;
             else o2 = v;
@@ -174,10 +206,13 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_pixels(const KArgs A)
         const uint32_t r = tile / A.tiles_per_row;                 // row within this launch (uniform)
         const uint32_t x = (tile - r * A.tiles_per_row) * BLOCK + threadIdx.x;
         const uint32_t y = A.y0 + (r / A.blk_rows) * A.blk_stride + r % A.blk_rows;
-        const double *yrow = A.yvals + (size_t)r * A.n_yvals;
         double o0 = 0.0, o1 = 0.0, o2 = 0.0;
-        run_tape<TAPE_LDS, false>(A, tape_lds, consts_lds, slots, spill_base, spill_stride, yrow,
-                                  (double)x, (double)y, nullptr, o0, o1, o2);      // p = [x as f64, y as f64]
+        uint32_t unused = 0;
+        Item I{};
+        I.yrow = A.yvals + (size_t)r * A.n_yvals;
+        I.gk = A.guard_w32 ? A.gbits + ((size_t)(r / A.guard_rows) * A.tiles_per_row + (tile - r * A.tiles_per_row)) * A.guard_w32 : nullptr;
+        I.X = (double)x; I.Y = (double)y;                                            // p = [x as f64, y as f64]
+        run_tape<TAPE_LDS, MODE_PIXEL>(A, A.tape, A.n_ops, tape_lds, consts_lds, slots, spill_base, spill_stride, I, o0, o1, o2, unused);
         if (x < A.w) {
             const size_t p = ((size_t)r * A.w + x) * 3;
             if (A.rgb64) { A.rgb64[p] = o0; A.rgb64[p + 1] = o1; A.rgb64[p + 2] = o2; }
@@ -190,8 +225,9 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_pixels(const KArgs A)
     }
 }
 
-// ROW kernel: one work-item per image row evaluates the ROW section and writes
-// the row's y values.  Tiny (rows x n_row_ops); slots live in LDS or spill.
+// ROW kernel: one work-item per image row evaluates the ROW section (in guard-bit mode: the part of it that the
+// operand y values depend on) and writes the row's y values.  Guards it evaluates are bounded over the whole row.
+// Tiny (rows x n_row_ops); slots live in LDS or spill.
 __global__ void __launch_bounds__(BLOCK) maray_tape_rows(const KArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -201,8 +237,39 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_rows(const KArgs A)
     const uint32_t r = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t rr = r < A.rows ? r : A.rows - 1;               // keep the wave uniform; surplus lanes recompute the last row
     double o0, o1, o2;
-    run_tape<false, true>(A, nullptr, nullptr, slots, spill_base, spill_stride, nullptr,
-                          0.0, (double)(A.y0 + (rr / A.blk_rows) * A.blk_stride + rr % A.blk_rows), A.yout + (size_t)rr * A.n_yvals, o0, o1, o2);
+    uint32_t unused = 0;
+    Item I{};
+    I.Y = (double)(A.y0 + (rr / A.blk_rows) * A.blk_stride + rr % A.blk_rows);
+    I.xmin = 0.0; I.xmax = (double)(A.w - 1u); I.ymin = I.Y; I.ymax = I.Y;
+    I.yout = A.yout + (size_t)rr * A.n_yvals;
+    run_tape<false, MODE_ROW>(A, A.tape, A.n_ops, nullptr, nullptr, slots, spill_base, spill_stride, I, o0, o1, o2, unused);
+}
+
+// GUARDS kernel: one work-item per rectangle of guard_rows rows x 256 pixels, blockIdx.y = job (8 guards = one byte
+// of the rectangle's guard bits; its tape is the cone of those guards: short jobs, many wavefronts -- each is one
+// dependent chain).  XMIN..YMAX = the rectangle's ends.
+__global__ void __launch_bounds__(BLOCK) maray_tape_guards(const KArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *slots = (double *)smem;
+    const uint32_t spill_stride = gridDim.x * gridDim.y * BLOCK;
+    double *spill_base = A.spill ? A.spill + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x : nullptr;
+    const uint32_t n_groups = (A.rows + A.guard_rows - 1) / A.guard_rows;
+    const uint32_t n_items = n_groups * A.tiles_per_row;
+    const uint32_t it = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t item = it < n_items ? it : n_items - 1;         // keep the wave uniform
+    const uint32_t grp = item / A.tiles_per_row, tx = item - grp * A.tiles_per_row;
+    const uint32_t r = grp * A.guard_rows, r_last = r + A.guard_rows - 1 < A.rows - 1 ? r + A.guard_rows - 1 : A.rows - 1;
+    const uint32_t xlo = tx * BLOCK, xhi = xlo + BLOCK - 1 < A.w - 1 ? xlo + BLOCK - 1 : A.w - 1;
+    const uint32_t job = blockIdx.y;
+    double o0, o1, o2;
+    uint32_t bits = 0;
+    Item I{};
+    // a group never straddles two row blocks (the host picks guard_rows | blk_rows): its image rows are consecutive
+    I.Y = (double)(A.y0 + (r / A.blk_rows) * A.blk_stride + r % A.blk_rows);
+    I.xmin = (double)xlo; I.xmax = (double)xhi; I.ymin = I.Y; I.ymax = I.Y + (double)(r_last - r);
+    run_tape<false, MODE_GUARDS>(A, A.tape + A.job_off[job], A.job_len[job], nullptr, nullptr, slots, spill_base, spill_stride, I, o0, o1, o2, bits);
+    if (it < n_items) ((unsigned char *)A.gbits)[(size_t)item * (A.guard_w32 * 4u) + job] = (unsigned char)bits;
 }
 
 #define HIP_TRY(expr)                                                                              \
@@ -223,6 +290,14 @@ struct TapeBackend final : Backend {
     std::vector<unsigned char *> d_tex_rgb;
     double *d_yvals = nullptr; size_t yvals_cap = 0;
     double *d_spill = nullptr; size_t spill_cap = 0;
+    // Guards per rectangle of pixels (include/maray_tape.h, SPEC XMIN..YMIN): when no guard reads Y, the ROW tape is
+    // cut into the cone of the operand y values (run per row) and the cones of the guards, 32 to a job (run per
+    // rectangle of 8 rows x 256 pixels by maray_tape_guards); the pixel kernel then reads guard bits.
+    bool tile_guards = false;
+    uint32_t n_ynum = 0, n_row_ops_rows = 0, n_guard_jobs = 0, n_guard_w32 = 0;
+    uint64_t *d_guard_ops = nullptr;
+    uint32_t *d_job_off = nullptr, *d_job_len = nullptr;
+    uint32_t *d_gbits = nullptr; size_t gbits_cap = 0;
     unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;
     double *d_rgb64 = nullptr; size_t rgb64_cap = 0;
     hipStream_t own_stream = nullptr;
@@ -236,6 +311,7 @@ struct TapeBackend final : Backend {
         (void)hipFree(d_row_ops); (void)hipFree(d_pix_ops); (void)hipFree(d_consts); (void)hipFree(d_tex);
         for (auto p : d_tex_rgb) (void)hipFree(p);
         (void)hipFree(d_yvals); (void)hipFree(d_spill); (void)hipFree(d_rgb8); (void)hipFree(d_rgb64);
+        (void)hipFree(d_guard_ops); (void)hipFree(d_job_off); (void)hipFree(d_job_len); (void)hipFree(d_gbits);
         if (own_stream) (void)hipStreamDestroy(own_stream);
     }
 
@@ -252,7 +328,36 @@ struct TapeBackend final : Backend {
             HIP_TRY(hipMalloc(dst, bytes ? bytes : 8));
             if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
         };
-        up(prog.row_ops, (size_t)prog.n_row_ops * 8, (void **)&d_row_ops);
+        n_ynum = numeric_yvals(prog);
+        n_row_ops_rows = prog.n_row_ops;
+        const uint32_t n_guards = prog.n_yvals - n_ynum;
+        tile_guards = n_guards > 0 && prog.n_row_ops > 0 && !any_guard_reads_y(prog) && !getenv("MARAY_TAPE_ROW_GUARDS");
+        if (tile_guards) {
+            const RowTapeDeps deps = row_tape_deps(prog);
+            std::vector<uint32_t> num_outs;
+            for (uint32_t o : deps.outs) if (MARAY_INS_AUX(prog.row_ops[o]) < n_ynum) num_outs.push_back(o);
+            const std::vector<uint64_t> rows_tape = compact_tape(row_tape_cone(prog, deps, num_outs, nullptr));
+            n_row_ops_rows = (uint32_t)rows_tape.size();
+            up(rows_tape.data(), rows_tape.size() * 8, (void **)&d_row_ops);
+            n_guard_jobs = (n_guards + 7) / 8;
+            n_guard_w32 = (n_guards + 31) / 32;
+            std::vector<uint64_t> all;
+            std::vector<uint32_t> off(n_guard_jobs), len(n_guard_jobs);
+            for (uint32_t j = 0; j < n_guard_jobs; j++) {
+                std::vector<uint32_t> outs;
+                for (uint32_t o : deps.outs) {
+                    const uint32_t aux = MARAY_INS_AUX(prog.row_ops[o]);
+                    if (aux >= n_ynum + 8 * j && aux < n_ynum + 8 * (j + 1)) outs.push_back(o);
+                }
+                const std::vector<uint64_t> t = compact_tape(row_tape_cone(prog, deps, outs, nullptr));
+                off[j] = (uint32_t)all.size(); len[j] = (uint32_t)t.size();
+                all.insert(all.end(), t.begin(), t.end());
+            }
+            up(all.data(), all.size() * 8, (void **)&d_guard_ops);
+            up(off.data(), off.size() * 4, (void **)&d_job_off);
+            up(len.data(), len.size() * 4, (void **)&d_job_len);
+        } else
+            up(prog.row_ops, (size_t)prog.n_row_ops * 8, (void **)&d_row_ops);
         up(prog.pix_ops, (size_t)prog.n_pix_ops * 8, (void **)&d_pix_ops);
         up(prog.consts, (size_t)prog.n_consts * 8, (void **)&d_consts);
         std::vector<MarayTex> descs(n_tex ? n_tex : 1);
@@ -302,10 +407,21 @@ struct TapeBackend final : Backend {
         (void)hipGetLastError();        // the launches below are checked with hipGetLastError(): drop what an earlier, unrelated call left
         if (!ext_yvals) ensure(d_yvals, yvals_cap, (size_t)rows * std::max<uint32_t>(P.n_yvals, 1));
         if (ext_yvals) rows_pass = false;
+        // guard bits per rectangle: only with this back-end's own ROW pass (a caller's y-value table carries the guards
+        // as y values bounded over the row), and only if a group of rows never straddles two row blocks
+        const bool bits = tile_guards && !ext_yvals;
+        const uint32_t guard_rows = (bits && (rb.block_rows >= rows || rb.block_rows % 8 == 0)) ? 8u : 1u;
+        const uint32_t tiles_per_row = (w + BLOCK - 1) / BLOCK;
+        const uint32_t n_groups = (rows + guard_rows - 1) / guard_rows;
+        if (bits) {
+            const size_t had = gbits_cap;
+            ensure(d_gbits, gbits_cap, (size_t)n_groups * tiles_per_row * n_guard_w32);
+            if (gbits_cap != had) HIP_TRY(hipMemsetAsync(d_gbits, 0, gbits_cap * 4, st));     // bytes past the last job are never written
+        }
         if (rows_pass && P.n_row_ops) {
             KArgs R{};
             R.tape = d_row_ops; R.consts = d_consts; R.yout = d_yvals; R.tex = d_tex;
-            R.n_ops = P.n_row_ops; R.n_consts = P.n_consts; R.n_yvals = P.n_yvals;
+            R.n_ops = n_row_ops_rows; R.n_consts = P.n_consts; R.n_yvals = P.n_yvals;
             R.n_slots = P.n_row_slots; R.n_lds_slots = row_lds_slots;
             R.w = w; R.y0 = y0; R.rows = rows; R.blk_rows = rb.block_rows; R.blk_stride = rb.block_stride;
             const uint32_t grid = (rows + BLOCK - 1) / BLOCK;
@@ -315,6 +431,22 @@ struct TapeBackend final : Backend {
             }
             hipLaunchKernelGGL(maray_tape_rows, dim3(grid), dim3(BLOCK), row_lds_bytes, st, R);
             HIP_TRY(hipGetLastError());
+            if (bits) {
+                KArgs G = R;
+                G.tape = d_guard_ops; G.yout = nullptr;
+                G.gbits = d_gbits; G.job_off = d_job_off; G.job_len = d_job_len;
+                G.guard_first = n_ynum; G.guard_w32 = n_guard_w32; G.guard_rows = guard_rows; G.tiles_per_row = tiles_per_row;
+                const uint64_t items = (uint64_t)n_groups * tiles_per_row;
+                if (items > 0x7FFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
+                const uint32_t ggrid = (uint32_t)((items + BLOCK - 1) / BLOCK);
+                G.spill = nullptr;
+                if (P.n_row_slots > row_lds_slots) {
+                    ensure(d_spill, spill_cap, std::max(spill_cap, (size_t)(P.n_row_slots - row_lds_slots) * ggrid * n_guard_jobs * BLOCK));
+                    G.spill = d_spill;
+                }
+                hipLaunchKernelGGL(maray_tape_guards, dim3(ggrid, n_guard_jobs), dim3(BLOCK), row_lds_bytes, st, G);
+                HIP_TRY(hipGetLastError());
+            }
         }
         KArgs A{};
         A.tape = d_pix_ops; A.consts = d_consts; A.yvals = ext_yvals ? ext_yvals : d_yvals; A.tex = d_tex;
@@ -323,7 +455,8 @@ struct TapeBackend final : Backend {
         A.n_ops = P.n_pix_ops; A.n_consts = P.n_consts; A.n_yvals = P.n_yvals;
         A.n_slots = P.n_pix_slots; A.n_lds_slots = n_lds_slots;
         A.w = w; A.y0 = y0; A.rows = rows; A.blk_rows = rb.block_rows; A.blk_stride = rb.block_stride;
-        A.tiles_per_row = (w + BLOCK - 1) / BLOCK;
+        A.tiles_per_row = tiles_per_row;
+        if (bits) { A.gbits = d_gbits; A.guard_first = n_ynum; A.guard_w32 = n_guard_w32; A.guard_rows = guard_rows; }
         const uint64_t tiles = (uint64_t)A.tiles_per_row * rows;
         if (tiles > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
         A.n_tiles = (uint32_t)tiles;
