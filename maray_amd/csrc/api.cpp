@@ -153,7 +153,7 @@ void validate_program(const maray_program &p)
 extern "C" {
 
 const char *maray_last_error(void) { return g_err.c_str(); }
-const char *maray_version(void) { return "maray_amd 0.1 (gfx950; tape v1; mirrors maray 0.3.8)"; }
+const char *maray_version(void) { return "maray_amd 0.1 (gfx950; tape v2; mirrors maray 0.3.8)"; }
 
 // ---- scenes ------------------------------------------------------------------
 int maray_scene_from_bytes(const uint8_t *buf, size_t len, maray_scene **out)
