@@ -65,6 +65,10 @@ def test_well_formed_tape_passes_validation():
     ('value defined only inside a skipped region read after it',
      [ins(OP['STEP'], dst=1, a=X), ins(OP['SKIPZ'], 2, dst=2, a=ACC), ins(OP['STEP'], dst=3, a=Y), ins(OP['MIN'], dst=2, a=ref(SLOT, 1), b=ACC),
       ins(OP['OUT'], 0, a=ref(SLOT, 3))], {}),
+    ('span special (XMIN) in the PIXEL section', [ins(OP['ADD'], dst=0, a=X, b=ref(SPEC, 4))] + GOOD, {}),
+    ('span special (YMAX) in the PIXEL section', [ins(OP['ADD'], dst=0, a=X, b=ref(SPEC, 5))] + GOOD, {}),
+    ('special operand out of range', [ins(OP['ADD'], dst=0, a=X, b=ref(SPEC, 7))] + GOOD, {}),
+    ('X in the ROW section', GOOD, dict(n_yvals=1, row_ops=[ins(OP['ADD'], dst=0, a=X, b=Y), ins(OP['OUT'], 0, a=ACC)])),
     ('OUT inside a skip region',
      [ins(OP['STEP'], dst=1, a=X), ins(OP['SKIPZ'], 2, dst=2, a=ACC), ins(OP['OUT'], 0, a=Y), ins(OP['MIN'], dst=2, a=ref(SLOT, 1), b=ref(SLOT, 1))], {}),
 ])
@@ -72,6 +76,15 @@ def test_malformed_tapes_are_rejected(name, ops, kw):
     rc, msg = create(ops, **kw)
     assert rc in (-1, -7), (name, rc, msg)
     assert msg
+
+
+def test_span_specials_are_accepted_in_the_row_section():
+    """XMIN / XMAX / YMIN / YMAX: the ends of the span of pixels a guard bounds its boolean over (tape v2)."""
+    row = [ins(OP['ADD'], dst=0, a=ref(SPEC, 3), b=ref(SPEC, 4)), ins(OP['ADD'], dst=1, a=ref(SPEC, 5), b=ref(SPEC, 6)),
+           ins(OP['MIN'], dst=2, a=ref(SLOT, 0), b=ref(SLOT, 1)), ins(OP['OUT'], 0, a=ACC)]
+    pix = [ins(OP['ADD'], dst=0, a=X, b=ref(YVAL, 0))] + GOOD[1:]
+    rc, msg = create(pix, n_yvals=1, row_ops=row)
+    assert rc in (0, -8), msg
 
 
 def test_null_arguments_are_errors_not_crashes():
