@@ -15,13 +15,14 @@ typedef unsigned long long mr_mask;
 #define MR_NONE 0ull
 #define mr_ballot(c) __builtin_amdgcn_ballot_w64(c)            /* per-lane condition -> mask (v_cmp writes it) */
 
-// mask -> the f64 it stands for, per lane: {hi, 0} with hi = m[lane] ? on : off, one v_cndmask_b32 that reads the
-// mask straight from its SGPR pair.  (Inline asm rather than __builtin_amdgcn_inverse_ballot_w64: a process
+// mask -> the f64 it stands for, per lane: {hi, 0} with hi = m[lane] ? on : off, one v_cndmask_b32 on the mask.  (Inline asm rather than __builtin_amdgcn_inverse_ballot_w64: a process
 // that imported PyTorch first compiles with PyTorch's bundled ROCm 7.0 hiprtc, which lacks that builtin.)
 MARAY_DEV double mr_mask_f64(mr_mask m, unsigned on, unsigned off)
 {
+    // The mask goes through VCC: with an "s" operand the compiler may hand over EXEC itself (a mask that is ballot(true)
+    // IS exec), which v_cndmask cannot encode as its selector -- the upper 32 lanes then came out wrong.
     unsigned hi;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(off), "v"(on), "s"(m));
+    asm("s_mov_b64 vcc, %3\n\tv_cndmask_b32_e32 %0, %1, %2, vcc" : "=v"(hi) : "v"(off), "v"(on), "s"(m) : "vcc");
     return __builtin_bit_cast(double, (unsigned long long)hi << 32);
 }
 // a value every lane holds alike (read from LDS) -> SGPR pair

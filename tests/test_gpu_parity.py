@@ -328,3 +328,10 @@ def test_guarded_shapes_through_inf_and_nan():
     """The scene of tests/test_lowering.py's soundness test on the device, all three evaluators, ragged width."""
     gpu_vs_oracle(encode((192, 24), scenes.shapes_through_inf_and_nan()), 192, 24, [(0, 24)])
     gpu_vs_oracle(encode((700, 40), scenes.shapes_through_inf_and_nan()), 700, 40, [(0, 40), (3, 29)])
+
+
+def test_a_boolean_that_is_true_on_every_lane_materialises_on_all_64():
+    """Step(x) is true for every pixel: its lane mask is EXEC itself.  The select that turns a mask into an f64 must
+    not be handed EXEC as its selector (the upper 32 lanes of every wavefront came out 0)."""
+    c = [add(step(x()), y()), mul(add(step(x()), nat(2)), x()), sub(nat(7), step(mul(x(), y())))]
+    gpu_vs_oracle(encode((200, 3), c), 200, 3, [(0, 3)])
