@@ -90,6 +90,7 @@ struct Emitter {
         Kind kind = DBL;
         std::string d;   // name / literal of the double, empty until materialised
         std::string b;   // name / literal of the lane mask (BOOL, NEGBOOL)
+        uint32_t d_scope = 0;   // the region (C++ block) the materialised double was declared in; 0 = the kernel's own block
     };
     const maray_program &P;
     std::string out;
@@ -148,8 +149,14 @@ struct Emitter {
             }
         };
         // the double form of a value, materialising it once if needed
+        struct Open { uint32_t end; bool as_bool; bool nz; uint32_t id; };
+        std::vector<Open> open;     // SKIPZ / SKIPNZ regions being emitted, innermost last
+        uint32_t next_scope = 1;
         auto dbl = [&](Val *v, const char *hint, uint32_t i, int which) -> std::string {
-            if (!v->d.empty()) return v->d;
+            // a mask defined outside a region may have been materialised inside one: that variable is out of scope now
+            bool in_scope = v->d_scope == 0;
+            for (const Open &o : open) in_scope |= o.id == v->d_scope;
+            if (!v->d.empty() && in_scope) return v->d;
             if (v->b == "MR_NONE") return v->d = v->kind == BOOL ? "0.0" : "(-0.0)";
             if (v->b == "MR_ALL") return v->d = v->kind == BOOL ? "1.0" : "(-1.0)";
             snprintf(name, sizeof name, "%s%u_%c", hint, i, which ? 'b' : 'a');
@@ -157,11 +164,10 @@ struct Emitter {
             out += name;
             out += v->kind == BOOL ? " = mr_pos(" + v->b + ");\n" : " = mr_neg01(" + v->b + ");\n";
             v->d = name;
+            v->d_scope = open.empty() ? 0 : open.back().id;
             return v->d;
         };
 
-        struct Open { uint32_t end; bool as_bool; bool nz; };
-        std::vector<Open> open;     // SKIPZ / SKIPNZ regions being emitted, innermost last
         std::vector<uint8_t> forced(n, 0);      // op ends a region known at compile time to be skipped: its value is 0 (1) or 1 (2)
         for (uint32_t i = 0; i < n; i++) {
             const uint64_t ins = ops[i];
@@ -209,7 +215,7 @@ struct Emitter {
                 // regions are entered rarely (chess: 2-20 %): mark them unlikely so that the block placement keeps the
                 // skip path as the fall-through and moves the region bodies out of line (taken jumps stall on instruction fetch)
                 out += "    if (__builtin_expect(" + cond + ", 0)) {\n";
-                open.push_back(Open{end, typed_bool, nz});
+                open.push_back(Open{end, typed_bool, nz, next_scope++});
                 ktab_block.clear();
                 continue;
             }

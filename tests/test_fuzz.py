@@ -15,8 +15,8 @@ from test_lowering import same_f64
 W, H = 83, 9          # ragged: not a multiple of the wavefront
 
 
-def lowered(seed, n_tex):
-    data = encode((W, H), scene(seed, n_tex=n_tex))
+def lowered(seed, n_tex, w=W, h=H):
+    data = encode((w, h), scene(seed, n_tex=n_tex))
     try:
         return data, M.Scene(data).lower()
     except M.MarayError as e:

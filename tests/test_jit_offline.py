@@ -66,3 +66,17 @@ def test_row_section_is_cut_into_chunks(chess_bytes):
     assert guards_src.count('    case ') == (n_guards + 7) // 8        # 8 guards per job: many short wavefronts
     assert 'XMIN' in guards_src and 'XMIN' not in rows_src.split('switch')[1]      # only guards depend on the span
     build(tape)        # compiles the ROW kernel as well
+
+
+def test_random_scenes_build():
+    """The generated sources of random scenes compile (both kernels).  Seeds 1270..1289 include one where a lane mask
+    defined outside a region was first materialised as an f64 inside it and used again after it (a name out of scope)."""
+    from test_fuzz import lowered
+    built = 0
+    for seed in list(range(0, 60, 3)) + list(range(1270, 1290)):
+        _, tape = lowered(seed, 2 if seed % 3 == 0 else 0)
+        if tape is None:
+            continue
+        build(tape)
+        built += 1
+    assert built >= 35

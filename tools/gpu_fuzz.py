@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/gpu_fuzz.py LO HI — one-off wider sweep of tests/test_fuzz.py's random scenes on the GPU box: every evaluator
+"""tools/gpu_fuzz.py LO HI [W H] — one-off wider sweep of tests/test_fuzz.py's random scenes on the GPU box: every evaluator
 against the oracle, f64 planes bit for bit and RGB8 byte for byte.  Prints progress; exits non-zero on a mismatch."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,12 +13,14 @@ from test_lowering import same_f64
 import tape_eval
 
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
+if len(sys.argv) > 4:
+    W, H = int(sys.argv[3]), int(sys.argv[4])          # another geometry: several tiles per row, whole groups of rows
 tex = scenes.textures(scale=64)
 bad = done = guarded = 0
 t0 = time.time()
 for seed in range(lo, hi):
     n_tex = 2 if seed % 3 == 0 else 0
-    data, tape = lowered(seed, n_tex)
+    data, tape = lowered(seed, n_tex, W, H)
     if tape is None:
         continue
     t = tex if n_tex else None
