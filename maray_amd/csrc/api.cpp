@@ -401,6 +401,26 @@ int maray_jit_source_rows(const maray_program *prog, char **src_out, uint32_t *n
     });
 }
 
+int maray_row_cone(const maray_program *prog, uint32_t first_out, uint32_t n_out, uint64_t **ops_out, uint32_t *n_ops_out, uint32_t *n_slots_out)
+{
+    return guard([&] {
+        REQUIRE(prog && ops_out && n_ops_out && n_slots_out, "null argument");
+        validate_program(*prog);
+        const RowTapeDeps deps = row_tape_deps(*prog);
+        std::vector<uint32_t> outs;
+        for (uint32_t o : deps.outs) {
+            const uint32_t k = MARAY_INS_AUX(prog->row_ops[o]);
+            if (k >= first_out && k - first_out < n_out) outs.push_back(o);
+        }
+        std::vector<uint64_t> t = compact_tape(row_tape_cone(*prog, deps, outs, nullptr));
+        *n_slots_out = renumber_slots(t);
+        *n_ops_out = (uint32_t)t.size();
+        *ops_out = (uint64_t *)malloc(t.size() * 8 + 8);
+        if (!*ops_out) throw Error{MARAY_E_INTERNAL, "out of memory"};
+        memcpy(*ops_out, t.data(), t.size() * 8);
+    });
+}
+
 int maray_jit_build(const maray_program *prog, void **code_out, size_t *len_out)
 {
     return guard([&] {

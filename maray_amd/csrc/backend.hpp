@@ -58,6 +58,8 @@ RowTapeDeps row_tape_deps(const maray_program &P);
 std::vector<uint64_t> row_tape_cone(const maray_program &P, const RowTapeDeps &d, const std::vector<uint32_t> &outs, size_t *cost);
 // The same tape without its NOPs (SKIP op counts adjusted).
 std::vector<uint64_t> compact_tape(const std::vector<uint64_t> &tape);
+// Renumbers the value slots of a compacted tape by liveness; returns the number of slots it then uses.
+uint32_t renumber_slots(std::vector<uint64_t> &tape);
 // Does any guard (a y value that only gates SKIP ops) have SPEC Y in its cone?  If none does, guards may be evaluated
 // once for a group of rows (YMIN / YMAX, include/maray_tape.h).
 bool any_guard_reads_y(const maray_program &P);

@@ -252,24 +252,28 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_guards(const KArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *slots = (double *)smem;
-    const uint32_t spill_stride = gridDim.x * gridDim.y * BLOCK;
-    double *spill_base = A.spill ? A.spill + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x : nullptr;
+    const uint32_t spill_stride = gridDim.x * BLOCK;
+    double *spill_base = A.spill ? A.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
     const uint32_t n_groups = (A.rows + A.guard_rows - 1) / A.guard_rows;
     const uint32_t n_items = n_groups * A.tiles_per_row;
-    const uint32_t it = blockIdx.x * BLOCK + threadIdx.x;
-    const uint32_t item = it < n_items ? it : n_items - 1;         // keep the wave uniform
-    const uint32_t grp = item / A.tiles_per_row, tx = item - grp * A.tiles_per_row;
-    const uint32_t r = grp * A.guard_rows, r_last = r + A.guard_rows - 1 < A.rows - 1 ? r + A.guard_rows - 1 : A.rows - 1;
-    const uint32_t xlo = tx * BLOCK, xhi = xlo + BLOCK - 1 < A.w - 1 ? xlo + BLOCK - 1 : A.w - 1;
-    const uint32_t job = blockIdx.y;
-    double o0, o1, o2;
-    uint32_t bits = 0;
-    Item I{};
-    // a group never straddles two row blocks (the host picks guard_rows | blk_rows): its image rows are consecutive
-    I.Y = (double)(A.y0 + (r / A.blk_rows) * A.blk_stride + r % A.blk_rows);
-    I.xmin = (double)xlo; I.xmax = (double)xhi; I.ymin = I.Y; I.ymax = I.Y + (double)(r_last - r);
-    run_tape<false, MODE_GUARDS>(A, A.tape + A.job_off[job], A.job_len[job], nullptr, nullptr, slots, spill_base, spill_stride, I, o0, o1, o2, bits);
-    if (it < n_items) ((unsigned char *)A.gbits)[(size_t)item * (A.guard_w32 * 4u) + job] = (unsigned char)bits;
+    const uint32_t item_blocks = (n_items + BLOCK - 1) / BLOCK;
+    // blocks stride over (job, block of items) pairs: the grid, and with it the spill area, stays bounded for any image
+    for (uint32_t u = blockIdx.x; u < item_blocks * A.n_tiles /* = jobs */; u += gridDim.x) {
+        const uint32_t job = u / item_blocks;
+        const uint32_t it = (u - job * item_blocks) * BLOCK + threadIdx.x;
+        const uint32_t item = it < n_items ? it : n_items - 1;         // keep the wave uniform
+        const uint32_t grp = item / A.tiles_per_row, tx = item - grp * A.tiles_per_row;
+        const uint32_t r = grp * A.guard_rows, r_last = r + A.guard_rows - 1 < A.rows - 1 ? r + A.guard_rows - 1 : A.rows - 1;
+        const uint32_t xlo = tx * BLOCK, xhi = xlo + BLOCK - 1 < A.w - 1 ? xlo + BLOCK - 1 : A.w - 1;
+        double o0, o1, o2;
+        uint32_t bits = 0;
+        Item I{};
+        // a group never straddles two row blocks (the host picks guard_rows | blk_rows): its image rows are consecutive
+        I.Y = (double)(A.y0 + (r / A.blk_rows) * A.blk_stride + r % A.blk_rows);
+        I.xmin = (double)xlo; I.xmax = (double)xhi; I.ymin = I.Y; I.ymax = I.Y + (double)(r_last - r);
+        run_tape<false, MODE_GUARDS>(A, A.tape + A.job_off[job], A.job_len[job], nullptr, nullptr, slots, spill_base, spill_stride, I, o0, o1, o2, bits);
+        if (it < n_items) ((unsigned char *)A.gbits)[(size_t)item * (A.guard_w32 * 4u) + job] = (unsigned char)bits;
+    }
 }
 
 #define HIP_TRY(expr)                                                                              \
@@ -295,6 +299,8 @@ struct TapeBackend final : Backend {
     // rectangle of 8 rows x 256 pixels by maray_tape_guards); the pixel kernel then reads guard bits.
     bool tile_guards = false;
     uint32_t n_ynum = 0, n_row_ops_rows = 0, n_guard_jobs = 0, n_guard_w32 = 0;
+    uint32_t rows_slots = 0, guard_slots = 0;          // value slots of the cut tapes (renumbered by liveness)
+    uint32_t guard_lds_slots = 0, guard_lds_bytes = 0;
     uint64_t *d_guard_ops = nullptr;
     uint32_t *d_job_off = nullptr, *d_job_len = nullptr;
     uint32_t *d_gbits = nullptr; size_t gbits_cap = 0;
@@ -336,7 +342,8 @@ struct TapeBackend final : Backend {
             const RowTapeDeps deps = row_tape_deps(prog);
             std::vector<uint32_t> num_outs;
             for (uint32_t o : deps.outs) if (MARAY_INS_AUX(prog.row_ops[o]) < n_ynum) num_outs.push_back(o);
-            const std::vector<uint64_t> rows_tape = compact_tape(row_tape_cone(prog, deps, num_outs, nullptr));
+            std::vector<uint64_t> rows_tape = compact_tape(row_tape_cone(prog, deps, num_outs, nullptr));
+            rows_slots = renumber_slots(rows_tape);
             n_row_ops_rows = (uint32_t)rows_tape.size();
             up(rows_tape.data(), rows_tape.size() * 8, (void **)&d_row_ops);
             n_guard_jobs = (n_guards + 7) / 8;
@@ -349,7 +356,8 @@ struct TapeBackend final : Backend {
                     const uint32_t aux = MARAY_INS_AUX(prog.row_ops[o]);
                     if (aux >= n_ynum + 8 * j && aux < n_ynum + 8 * (j + 1)) outs.push_back(o);
                 }
-                const std::vector<uint64_t> t = compact_tape(row_tape_cone(prog, deps, outs, nullptr));
+                std::vector<uint64_t> t = compact_tape(row_tape_cone(prog, deps, outs, nullptr));
+                guard_slots = std::max(guard_slots, renumber_slots(t));
                 off[j] = (uint32_t)all.size(); len[j] = (uint32_t)t.size();
                 all.insert(all.end(), t.begin(), t.end());
             }
@@ -380,8 +388,12 @@ struct TapeBackend final : Backend {
         n_lds_slots = (uint32_t)std::min<size_t>(prog.n_pix_slots, (lds_cap - base) / slot_bytes);
         lds_bytes = (uint32_t)(base + (size_t)n_lds_slots * slot_bytes);
         blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, lds_cap / std::max<uint32_t>(lds_bytes, 1)));
-        row_lds_slots = (uint32_t)std::min<size_t>(prog.n_row_slots, 65536 / slot_bytes);
+        if (!tile_guards) rows_slots = prog.n_row_slots;
+        row_lds_slots = (uint32_t)std::min<size_t>(rows_slots, 65536 / slot_bytes);
         row_lds_bytes = (uint32_t)(row_lds_slots * slot_bytes);
+        guard_lds_slots = (uint32_t)std::min<size_t>(guard_slots, 40);       // 80 KB: two blocks per CU; the rest spills
+        guard_lds_bytes = (uint32_t)(guard_lds_slots * slot_bytes);
+        if (tile_guards) HIP_TRY(hipFuncSetAttribute((const void *)maray_tape_guards, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
         if (lds_variant) {
             HIP_TRY(hipFuncSetAttribute((const void *)maray_tape_pixels<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
             kname = "maray_tape_pixels<true>";
@@ -422,11 +434,11 @@ struct TapeBackend final : Backend {
             KArgs R{};
             R.tape = d_row_ops; R.consts = d_consts; R.yout = d_yvals; R.tex = d_tex;
             R.n_ops = n_row_ops_rows; R.n_consts = P.n_consts; R.n_yvals = P.n_yvals;
-            R.n_slots = P.n_row_slots; R.n_lds_slots = row_lds_slots;
+            R.n_slots = rows_slots; R.n_lds_slots = row_lds_slots;
             R.w = w; R.y0 = y0; R.rows = rows; R.blk_rows = rb.block_rows; R.blk_stride = rb.block_stride;
             const uint32_t grid = (rows + BLOCK - 1) / BLOCK;
-            if (P.n_row_slots > row_lds_slots) {
-                ensure(d_spill, spill_cap, std::max(spill_cap, (size_t)(P.n_row_slots - row_lds_slots) * grid * BLOCK));
+            if (rows_slots > row_lds_slots) {
+                ensure(d_spill, spill_cap, std::max(spill_cap, (size_t)(rows_slots - row_lds_slots) * grid * BLOCK));
                 R.spill = d_spill;
             }
             hipLaunchKernelGGL(maray_tape_rows, dim3(grid), dim3(BLOCK), row_lds_bytes, st, R);
@@ -438,13 +450,16 @@ struct TapeBackend final : Backend {
                 G.guard_first = n_ynum; G.guard_w32 = n_guard_w32; G.guard_rows = guard_rows; G.tiles_per_row = tiles_per_row;
                 const uint64_t items = (uint64_t)n_groups * tiles_per_row;
                 if (items > 0x7FFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
-                const uint32_t ggrid = (uint32_t)((items + BLOCK - 1) / BLOCK);
+                const uint64_t units = ((items + BLOCK - 1) / BLOCK) * n_guard_jobs;        // (job, block of items) pairs
+                const uint32_t ggrid = (uint32_t)std::min<uint64_t>(units, (uint64_t)prop.multiProcessorCount * 2);
                 G.spill = nullptr;
-                if (P.n_row_slots > row_lds_slots) {
-                    ensure(d_spill, spill_cap, std::max(spill_cap, (size_t)(P.n_row_slots - row_lds_slots) * ggrid * n_guard_jobs * BLOCK));
+                G.n_slots = guard_slots; G.n_lds_slots = guard_lds_slots;
+                G.n_tiles = n_guard_jobs;                                                       // the GUARDS kernel reads its job count here
+                if (guard_slots > guard_lds_slots) {
+                    ensure(d_spill, spill_cap, std::max(spill_cap, (size_t)(guard_slots - guard_lds_slots) * ggrid * BLOCK));
                     G.spill = d_spill;
                 }
-                hipLaunchKernelGGL(maray_tape_guards, dim3(ggrid, n_guard_jobs), dim3(BLOCK), row_lds_bytes, st, G);
+                hipLaunchKernelGGL(maray_tape_guards, dim3(ggrid), dim3(BLOCK), guard_lds_bytes, st, G);
                 HIP_TRY(hipGetLastError());
             }
         }

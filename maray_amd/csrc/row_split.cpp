@@ -106,6 +106,78 @@ std::vector<uint64_t> compact_tape(const std::vector<uint64_t> &tape)
     return out;
 }
 
+// Renumbers the value slots of a (compacted) tape by liveness: a slot is free again after the last op that reads the
+// value it holds.  The cone of a few outputs keeps the slot numbers the whole section was allocated with (hundreds, most
+// of them idle); an interpreter that keeps slots in LDS wants the few that are live at once.  Returns the slots used.
+//
+// A value = one definition.  A SKIP op with a dst defines, on the taken path, the value that the op ending its region
+// defines on the other: the two (and every SKIP op of a region nested at the same end) are ONE value, and its slot stays
+// taken from the outermost of those SKIP ops to the end op at least.  Liveness is taken over the linear order of the
+// tape, which is conservative for either path through a region (nothing defined inside one is read after it).
+uint32_t renumber_slots(std::vector<uint64_t> &tape)
+{
+    const uint32_t n = (uint32_t)tape.size();
+    std::vector<int32_t> cur(MARAY_DST_NONE + 1, -1);       // original slot -> the value it holds now
+    std::vector<int32_t> value_of(n, -1);                   // op -> the value it defines (index of the first op that defines it)
+    std::vector<int32_t> last_use(n, -1);                   // value -> last op that needs its slot
+    std::vector<int32_t> use_a(n, -1), use_b(n, -1);        // op -> the value its slot operand reads
+    std::vector<int32_t> region_value(n, -1);               // end op -> value reserved by the SKIP op(s) of its region
+    auto read = [&](uint32_t ref, uint32_t j, std::vector<int32_t> &use) {
+        if (MARAY_REF_KIND(ref) != MARAY_K_SLOT) return;
+        const int32_t v = cur[MARAY_REF_INDEX(ref)];
+        use[j] = v;
+        if (v >= 0) last_use[v] = (int32_t)j;
+    };
+    for (uint32_t j = 0; j < n; j++) {
+        const uint64_t ins = tape[j];
+        const uint32_t op = MARAY_INS_OP(ins), dst = MARAY_INS_DST(ins);
+        if (op == MARAY_OP_NOP) continue;
+        if (op != MARAY_OP_TEXDIM) read(MARAY_INS_A(ins), j, use_a);
+        if (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) read(MARAY_INS_B(ins), j, use_b);
+        if (op == MARAY_OP_OUT || dst == MARAY_DST_NONE) continue;
+        if (op == MARAY_OP_SKIPZ || op == MARAY_OP_SKIPNZ) {
+            const uint32_t end = j + MARAY_INS_AUX(ins);
+            if (end >= n) continue;                          // (validated tapes never do this)
+            if (region_value[end] < 0) region_value[end] = (int32_t)j;
+            value_of[j] = region_value[end];
+            last_use[value_of[j]] = std::max(last_use[value_of[j]], (int32_t)end);
+        } else
+            value_of[j] = region_value[j] >= 0 ? region_value[j] : (int32_t)j;
+        cur[dst] = value_of[j];
+    }
+    std::vector<std::vector<int32_t>> dies(n);              // op -> values whose slot is free after it
+    for (uint32_t v = 0; v < n; v++) if (value_of[v] == (int32_t)v && last_use[v] >= 0) dies[last_use[v]].push_back((int32_t)v);
+    std::vector<int32_t> slot_of(n, -1);
+    std::vector<uint32_t> free_list;
+    uint32_t used = 0;
+    for (uint32_t j = 0; j < n; j++) {
+        const uint64_t ins = tape[j];
+        const uint32_t op = MARAY_INS_OP(ins);
+        if (op == MARAY_OP_NOP) continue;
+        uint32_t a = MARAY_INS_A(ins), b = MARAY_INS_B(ins), dst = MARAY_INS_DST(ins);
+        if (use_a[j] >= 0) a = MARAY_REF(MARAY_K_SLOT, (uint32_t)slot_of[use_a[j]]);
+        if (use_b[j] >= 0) b = MARAY_REF(MARAY_K_SLOT, (uint32_t)slot_of[use_b[j]]);
+        // operands are read before the result is written: a value that dies here may hand its slot to this op's result,
+        // unless it is this op's own value (the end of a region whose result nothing reads afterwards)
+        for (int32_t v : dies[j]) if (v != value_of[j]) free_list.push_back((uint32_t)slot_of[v]);
+        if (value_of[j] >= 0) {
+            const int32_t v = value_of[j];
+            if (v == (int32_t)j) {                           // a new value
+                if (last_use[v] < 0) dst = MARAY_DST_NONE;   // only ever consumed through ACC here
+                else {
+                    if (free_list.empty()) free_list.push_back(used++);
+                    slot_of[v] = (int32_t)free_list.back();
+                    free_list.pop_back();
+                    dst = (uint32_t)slot_of[v];
+                }
+            } else dst = (uint32_t)slot_of[v];               // continues the value its region's SKIP op reserved
+        }
+        for (int32_t v : dies[j]) if (v == value_of[j]) free_list.push_back((uint32_t)slot_of[v]);
+        tape[j] = MARAY_INS(op, MARAY_INS_AUX(ins), dst, a, b);
+    }
+    return used;
+}
+
 bool any_guard_reads_y(const maray_program &P)
 {
     const RowTapeDeps d = row_tape_deps(P);

@@ -235,3 +235,42 @@ def test_guards_stay_sound_where_values_overflow_or_turn_nan():
     assert same_f64(tape_eval.render_rows_waves(tape, w, 0, h, tile=64), want64)
     if n_read_y == 0:
         assert same_f64(tape_eval.render_rows_waves(tape, w, 0, h, tile=64, yrows=8), want64)
+
+
+def row_cone(tape, first, count):
+    import ctypes as C
+    L = M.lib()
+    L.maray_row_cone.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    ops, n, ns = C.POINTER(C.c_uint64)(), C.c_uint32(), C.c_uint32()
+    assert L.maray_row_cone(C.byref(tape.program), first, count, C.byref(ops), C.byref(n), C.byref(ns)) == 0, L.maray_last_error()
+    arr = np.ctypeslib.as_array(ops, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint64)
+    L.maray_free(ops)
+    return arr, ns.value
+
+
+def test_row_section_cut_by_outputs_keeps_every_value(chess_bytes):
+    """Both back-ends cut the ROW section by outputs (row_split.cpp): the cone of a set of y values as a tape of its own,
+    NOPs removed, SKIP regions kept, slots renumbered by liveness.  Each cone must reproduce exactly the outputs it was
+    cut for -- with SKIP ops taken or not -- and need far fewer slots than the section."""
+    s = M.Scene(chess_bytes)
+    s.rescale(4, 4)
+    tape = s.lower()
+    consts, row_ops, _ = tape.arrays()
+    info = tape.info
+    ys = np.arange(1500, 1500 + 64, dtype=np.float64)
+    span, yspan = (256, 511), (ys - ys % 8, ys - ys % 8 + 7)
+    full = tape_eval.run_section(row_ops, consts, info['n_row_slots'], None, ys, None, None, info['n_yvals'], w=4096, span=span, yspan=yspan)
+    worst = 0
+    for first, count in ((0, 73), (73, 219), (292, 8), (300, 8), (380, 8), (452, 8), (292, 168)):
+        ops, n_slots = row_cone(tape, first, count)
+        if count < 100:
+            worst = max(worst, n_slots)         # the cuts the interpreter makes: 8 guards to a job
+        assert 0 < len(ops) < len(row_ops) and n_slots <= info['n_row_slots']
+        for honor in (False, True):
+            part = tape_eval.run_section(ops, consts, max(n_slots, 1), None, ys, None, None, info['n_yvals'], honor, w=4096, span=span, yspan=yspan)
+            for k in range(info['n_yvals']):
+                if first <= k < first + count:
+                    assert part[k] is not None and same_f64(part[k], full[k]), (first, count, k, honor)
+                else:
+                    assert part[k] is None
+    assert worst <= 72          # what an interpreter has to keep in LDS per work-item: tens of slots, not hundreds
