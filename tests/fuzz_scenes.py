@@ -67,3 +67,42 @@ def scene(seed, depth=6, n_tex=0):
     id-keyed Cache stays value-transparent; scenes that still alias are skipped by the caller."""
     rng = random.Random(seed)
     return [_expr(rng, depth, [], n_tex) for _ in range(3)]
+
+
+def polygon_soup(seed, n, w, h):
+    """n random textured triangles painted over one another (max chain), the kind of scene `examples/chess.rs` builds
+    and the lowering's shape machinery targets: balanced OR trees, group and shape guards, private regions.  Vertices
+    are integers inside (and a little outside) the w x h image; each triangle carries a chess pattern in its own
+    barycentric frame; channels differ in which triangles they paint and in a gradient term."""
+    from marayb import chess, inside_triangle, to_uv
+    rng = random.Random(0x50117 + seed)
+    p = [x(), y()]
+    tris = []
+    for _ in range(n):
+        cx, cy = rng.randrange(0, w), rng.randrange(0, h)
+        r = rng.choice([6, 12, 25, 60])
+        pts = [(nat(max(0, cx + rng.randrange(-r, r + 1))), nat(max(0, cy + rng.randrange(-r, r + 1)))) for _ in range(3)]
+        if len({(a[1], b[1]) for a, b in pts}) < 3:
+            continue
+        inside = inside_triangle(pts, p)
+        uv = to_uv(pts, [(nat(0), nat(0)), (nat(1), nat(0)), (nat(0), nat(1))], p)
+        pattern = subst_xy(chess(rng.choice([2, 4, 6])), uv[0], uv[1])
+        tris.append(min_(inside, pattern) if rng.random() < 0.7 else inside)
+    if not tris:
+        tris = [step(sub(x(), nat(w)))]
+
+    def paint(items):
+        acc = items[0]
+        for t in items[1:]:
+            acc = max_(acc, t)
+        return acc
+    grad = mul(add(x(), mul(y(), nat(3))), div(nat(1), nat(w + 3 * h)))
+    return [mul(paint(tris), nat(255)), mul(max_(paint(tris[::2]), mul(grad, div(nat(1), nat(2)))), nat(255)),
+            mul(add(mul(paint(tris[1::2] or tris), div(nat(3), nat(4))), mul(grad, div(nat(1), nat(4)))), nat(255))]
+
+
+def subst_xy(e, ex, ey):
+    """e with X -> ex and Y -> ey (tuple expression trees)."""
+    if e[0] == 'X': return ex
+    if e[0] == 'Y': return ey
+    return tuple(subst_xy(c, ex, ey) if isinstance(c, tuple) and c and isinstance(c[0], str) else c for c in e)

@@ -67,3 +67,36 @@ def test_random_scenes_gpu_vs_oracle():
             assert np.array_equal(got8, want8), (seed, b)
         done += 1
     assert done >= 30
+
+
+def test_polygon_soups_lowering_vs_oracle():
+    """Many textured triangles painted over one another (what examples/chess.rs builds, at random): balanced OR trees,
+    group and shape guards, private regions -- evaluated with guards per row, per tile and per rectangle."""
+    from fuzz_scenes import polygon_soup
+    w, h = 256, 64
+    for seed in range(4):
+        data = encode((w, h), polygon_soup(seed, 24, w, h))
+        tape = M.Scene(data).lower()
+        assert tape.info['rebalanced_chains'] >= 3 and tape.info['private_regions'] >= 8
+        n_guards, n_read_y = tape_eval.guards_reading_y(tape)
+        assert n_guards >= 6 and n_read_y == 0
+        _, want64 = OScene(data).render_rows(w, h, 0, h)
+        assert same_f64(tape_eval.render_rows(tape, w, 0, h), want64), seed
+        assert same_f64(tape_eval.render_rows_waves(tape, w, 0, h), want64), seed
+        assert same_f64(tape_eval.render_rows_waves(tape, w, 0, h, tile=64, yrows=8), want64), seed
+
+
+@pytest.mark.gpu
+def test_polygon_soups_gpu_vs_oracle():
+    from fuzz_scenes import polygon_soup
+    w, h = 1024, 200
+    for seed in range(10, 16):
+        data = encode((w, h), polygon_soup(seed, 70, w, h))
+        tape = M.Scene(data).lower()
+        want8, want64 = OScene(data).render_rows(w, h, 0, h)
+        for b in (M.BACKEND_JIT, M.BACKEND_TAPE, M.BACKEND_TAPE_SMEM):
+            ctx = M.Context(tape, backend=b)
+            got8, got64 = ctx.render_rows(w, h, 0, h)
+            ctx.close()
+            assert same_f64(got64, want64), (seed, b)
+            assert np.array_equal(got8, want8), (seed, b)
