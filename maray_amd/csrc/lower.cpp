@@ -745,6 +745,21 @@ struct Lowerer {
         return 0;
     }
 
+    // Schedules, ahead of a region, what the region's cone reads but does not own.  Only the nodes the cone reads
+    // directly are visited (each brings its own sub-tree, with the regions that sub-tree deserves): walking every
+    // shared node bottom-up would schedule a shared shape's factors one by one and leave nothing to guard at its root.
+    void visit_shared(const std::vector<int32_t> &r, const std::unordered_set<int32_t> &cone, Section &sec) {
+        std::vector<int32_t> frontier;
+        for (int32_t v : r) {
+            if (!cone.count(v)) continue;
+            for (int32_t c : {g.n[v].a, g.n[v].b})
+                if (c >= 0 && in_section[c] && !visited[c] && !cone.count(c)) frontier.push_back(c);
+        }
+        std::sort(frontier.begin(), frontier.end());
+        frontier.erase(std::unique(frontier.begin(), frontier.end()), frontier.end());
+        for (int32_t v : frontier) visit(v, sec);
+    }
+
     void visit(int32_t i, Section &sec) {
         if (i < 0 || visited[i] || !in_section[i]) return;
         // Row-level short circuit: a y value proves this boolean 0 on the whole row -> skip all that only feeds it.
@@ -755,7 +770,7 @@ struct Lowerer {
             const std::vector<int32_t> r = reach(i);
             const std::unordered_set<int32_t> cone = self_cone(i, r);
             if (cone.size() >= MIN_ROW_REGION && cone.size() <= MAX_REGION / 2) {
-                for (int32_t v : r) if (!cone.count(v)) visit(v, sec);      // shared nodes stay unconditional
+                visit_shared(r, cone, sec);                                  // shared nodes stay unconditional
                 const size_t mark = sec.sched.size();
                 SItem sk; sk.node = rowub[i]; sk.target = i; sk.nz = 0;
                 sec.sched.push_back(sk);
@@ -789,7 +804,7 @@ struct Lowerer {
                     const std::vector<int32_t> r = reach(body);
                     const std::unordered_set<int32_t> cone = exclusive_cone(body, i, r);
                     if (cone.size() >= MIN_REGION && cone.count(body)) {
-                        for (int32_t v : r) if (!cone.count(v)) visit(v, sec);   // shared nodes: computed unconditionally
+                        visit_shared(r, cone, sec);                               // shared nodes: computed unconditionally
                         const size_t mark = sec.sched.size();
                         SItem sk; sk.node = guard; sk.target = i; sk.nz = kind == 2;
                         sec.sched.push_back(sk);
