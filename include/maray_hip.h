@@ -131,7 +131,8 @@ enum {
     MARAY_BACKEND_TAPE = 0,      /* tape interpreter kernel: tape + constants staged in LDS */
     MARAY_BACKEND_TAPE_SMEM = 1, /* tape interpreter kernel: tape streamed through the scalar cache */
     MARAY_BACKEND_JIT = 2,       /* tape specialised to straight-line HIP via hiprtc (GPU analogue of src/wasm.rs) */
-    MARAY_BACKEND_AUTO = 3       /* JIT; if hiprtc cannot build the scene, the scalar-cache tape interpreter */
+    MARAY_BACKEND_AUTO = 3       /* JIT up to 25,000 pixel ops (beyond, hiprtc takes minutes); else, or if hiprtc cannot build the
+                                    scene, the scalar-cache tape interpreter */
 };
 
 typedef struct maray_ctx_opts {

@@ -303,6 +303,9 @@ int maray_hip_ctx_create(int device, const maray_program *prog, const maray_text
         case MARAY_BACKEND_TAPE_SMEM: b = make_tape_backend(device, *prog, tex, n_tex, false); break;
         case MARAY_BACKEND_JIT: b = make_jit_backend(device, *prog, tex, n_tex); break;
         case MARAY_BACKEND_AUTO:
+            // the specialised kernel pays for itself in hiprtc time: seconds up to ~10^4 pixel ops, minutes beyond
+            // (a 49 k-op scene took 6.5 min to build); larger programs start on the interpreter, which needs none
+            if (prog->n_pix_ops > 25000) { b = make_tape_backend(device, *prog, tex, n_tex, false); break; }
             try { b = make_jit_backend(device, *prog, tex, n_tex); }
             catch (const Error &e) {
                 if (e.code == MARAY_E_NO_DEVICE) throw;
