@@ -199,7 +199,8 @@ struct Emitter {
                 if (row_guard && !nz && guard_words && MARAY_REF_INDEX(gref) >= guard_first) {
                     // a row bound: one bit of a guard word that sits in an SGPR since the kernel's prologue
                     const uint32_t k = MARAY_REF_INDEX(gref) - guard_first;
-                    cond = "(gq" + std::to_string(k / 64) + " & (1ull << " + std::to_string(k % 64) + ")) != 0ull";
+                    cond = guard_words <= 12 ? "(gq" + std::to_string(k / 64) + " & (1ull << " + std::to_string(k % 64) + ")) != 0ull"
+                                             : "(mr_uniform64(mr_gqt[" + std::to_string(k / 64) + "]) & (1ull << " + std::to_string(k % 64) + ")) != 0ull";
                 } else if (row_guard) {
                     // a y value is uniform over the block: test its bits on the scalar unit, no ballot, no VALU
                     const std::string k = std::to_string(MARAY_REF_INDEX(gref));
@@ -370,12 +371,13 @@ std::vector<std::vector<uint64_t>> split_row_tape(const maray_program &P, const 
 }
 
 // How the specialised kernels use the row guards of a program: as bits, 64 per word, one set per
-// 256-pixel tile of a row (guard_words = 0: not at all -- none, too many, or switched off).
+// 256-pixel tile of a row (guard_words = 0: not at all -- none, far too many, or switched off).  Up to 12 words a tile's
+// words sit in SGPRs; beyond, a guard test reads its word from LDS.
 uint32_t jit_guard_words(const maray_program &P)
 {
     const uint32_t n_guards = P.n_yvals - numeric_yvals(P);
     const uint32_t nw = (n_guards + 63) / 64;
-    return (jit_row_guards_enabled() && nw <= 12) ? nw : 0;
+    return (jit_row_guards_enabled() && nw <= 1024) ? nw : 0;       // 1024 words x 8 tiles = 64 KB of LDS
 }
 
 // Rows per guard evaluation: 8 when no guard's cone reads Y (every guard then bounds its boolean over the rows
@@ -496,7 +498,7 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
     if (n_gwords) { E.guard_first = n_ynum; E.guard_words = n_gwords; }
     if (y_lds) E.yv_name = "mr_ylds";
     if (y_lds) s += "__shared__ double mr_ylds[" + std::to_string(n_ynum) + "];\n";
-    if (E.guard_words) s += "__shared__ unsigned long long mr_gq[" + std::to_string(16 * E.guard_words) + "];     // <= 16 tiles per block\n";
+    if (E.guard_words) s += "__shared__ unsigned long long mr_gq[" + std::to_string((E.guard_words <= 12 ? 16 : 8) * E.guard_words) + "];     // the guard words of the block's tiles\n";
     const bool defer = may_defer_tiles(P);
     s += "__shared__ unsigned mr_slow_tile;\n"
          "__device__ inline double mr_defer_sin(double) { mr_slow_tile = 1u; return 0.0; }\n"
@@ -527,13 +529,19 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
     if (E.guard_words) {
         const std::string nw = std::to_string(E.guard_words);
         s += "    const unsigned tile0 = blockIdx.x * tiles, my_tiles = n_tx - tile0 < tiles ? n_tx - tile0 : tiles;\n"
-             "    const unsigned long long gs = threadIdx.x < my_tiles * " + nw + "u ? gbits[((size_t)((row_base + r) / yrows) * n_tx + tile0) * " + nw + "u + threadIdx.x] : 0ull;\n";
+             "    const unsigned long long *gsrc = gbits + ((size_t)((row_base + r) / yrows) * n_tx + tile0) * " + nw + "u;\n"
+             "    const unsigned long long gs = threadIdx.x < my_tiles * " + nw + "u ? gsrc[threadIdx.x] : 0ull;\n";
     }
     for (uint32_t k = 0; k < y_rounds; k++) {
         const std::string i = std::to_string(k * 256) + "u + threadIdx.x";
         s += "    if (" + i + " < " + std::to_string(n_ynum) + "u) mr_ylds[" + i + "] = ys" + std::to_string(k) + ";\n";
     }
-    if (E.guard_words) s += "    if (threadIdx.x < " + std::to_string(16 * E.guard_words) + "u) mr_gq[threadIdx.x] = gs;\n";
+    if (E.guard_words) {
+        const std::string cap = std::to_string((E.guard_words <= 12 ? 16 : 8) * E.guard_words);
+        s += "    if (threadIdx.x < " + cap + "u) mr_gq[threadIdx.x] = gs;\n";
+        if ((E.guard_words <= 12 ? 16 : 8) * E.guard_words > 256)       // more words than threads: the rest in rounds
+            s += "    for (unsigned i = 256u + threadIdx.x; i < my_tiles * " + std::to_string(E.guard_words) + "u; i += 256u) mr_gq[i] = gsrc[i];\n";
+    }
     s += "    __syncthreads();\n"
          "    const double Y = (double)(y0 + ((row_base + r) / blk_rows) * blk_stride + (row_base + r) % blk_rows);     // -> image row (RowBlocks)\n"
          "    unsigned long long mr_ybase = (unsigned long long)yrow;\n"
@@ -549,8 +557,11 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
          "    (void)yv; (void)yw;\n"
          "/*MR_KBASE*/";
     if (E.guard_words) {
-        for (uint32_t j = 0; j < E.guard_words; j++)
-            s += "    const mr_mask gq" + std::to_string(j) + " = mr_uniform64(mr_gq[t * " + std::to_string(E.guard_words) + "u + " + std::to_string(j) + "u]);\n";
+        if (E.guard_words <= 12)
+            for (uint32_t j = 0; j < E.guard_words; j++)
+                s += "    const mr_mask gq" + std::to_string(j) + " = mr_uniform64(mr_gq[t * " + std::to_string(E.guard_words) + "u + " + std::to_string(j) + "u]);\n";
+        else
+            s += "    const unsigned long long *mr_gqt = mr_gq + t * " + std::to_string(E.guard_words) + "u;        // this tile's guard words\n";
     }
     s += "    const unsigned x = x0 + threadIdx.x;\n"
          "    const double X = (double)x;\n"
@@ -572,9 +583,18 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
         // Two variants of the section: one for a tile with no guard bit set (every row-guarded region is the constant 0
         // there and the compiler folds what depends on it: for chess.maray all that is left is the background), one
         // for the general case.  One scalar test per tile picks; most tiles of a sparse scene take the short one.
-        std::string any = "gq0";
-        for (uint32_t j = 1; j < E.guard_words; j++) any += " | gq" + std::to_string(j);
-        s += "    if ((" + any + ") == 0ull) {\n";
+        if (E.guard_words <= 12) {
+            std::string any = "gq0";
+            for (uint32_t j = 1; j < E.guard_words; j++) any += " | gq" + std::to_string(j);
+            s += "    if ((" + any + ") == 0ull) {\n";
+        } else {        // every wavefront looks at all the words, 64 per ballot
+            s += "    mr_mask mr_any = 0ull;\n"
+                 "    for (unsigned i0 = 0; i0 < " + std::to_string(E.guard_words) + "u; i0 += 64u) {        // the same trips on every lane: mr_any stays uniform\n"
+                 "        const unsigned i = i0 + (threadIdx.x & 63u);\n"
+                 "        mr_any |= mr_ballot((i < " + std::to_string(E.guard_words) + "u ? mr_gqt[i] : 0ull) != 0ull);\n"
+                 "    }\n"
+                 "    if (mr_any == 0ull) {\n";
+        }
         E.assume_guards_zero = true;
         E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
         E.assume_guards_zero = false;
@@ -788,7 +808,7 @@ struct JitBackend final : Backend {
         // average) and blocks are the unit of load balance (chess @4096^2, tiles = 2 / 4 / 8 / 16: 68 / 59 / 52 / 58 us;
         // walking the rows in a scattered order to mix cheap and dear ones costs more in cache locality than it balances)
         unsigned tiles = has_sin ? 1u : (unsigned)std::min<uint64_t>(std::min<uint64_t>(8, n_tx), std::max<uint64_t>(1, n_tiles / 4096));
-        if (const char *e_ = getenv("MARAY_JIT_TILES")) if (!has_sin && atoi(e_) > 0) tiles = (unsigned)std::min(16, atoi(e_));      // tuning knob (the kernel stages guard words for <= 16 tiles)
+        if (const char *e_ = getenv("MARAY_JIT_TILES")) if (!has_sin && atoi(e_) > 0) tiles = (unsigned)std::min(n_gwords > 12 ? 8 : 16, atoi(e_));      // tuning knob (the kernel stages guard words for <= 16 / 8 tiles)
         const unsigned gx = (n_tx + tiles - 1) / tiles;
         if (n_tiles > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
         ensure(d_flags, flags_cap, (size_t)n_tiles + 1);                    // work list {count, tile, ...} of deferred tiles

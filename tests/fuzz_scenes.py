@@ -69,11 +69,12 @@ def scene(seed, depth=6, n_tex=0):
     return [_expr(rng, depth, [], n_tex) for _ in range(3)]
 
 
-def polygon_soup(seed, n, w, h):
+def polygon_soup(seed, n, w, h, mixed=True):
     """n random textured triangles painted over one another (max chain), the kind of scene `examples/chess.rs` builds
     and the lowering's shape machinery targets: balanced OR trees, group and shape guards, private regions.  Vertices
     are integers inside (and a little outside) the w x h image; each triangle carries a chess pattern in its own
-    barycentric frame; channels differ in which triangles they paint and in a gradient term."""
+    barycentric frame; channels differ in a gradient term and, with `mixed`, in which triangles they paint (every shape
+    is then shared by two OR trees)."""
     from marayb import chess, inside_triangle, to_uv
     rng = random.Random(0x50117 + seed)
     p = [x(), y()]
@@ -97,6 +98,9 @@ def polygon_soup(seed, n, w, h):
             acc = max_(acc, t)
         return acc
     grad = mul(add(x(), mul(y(), nat(3))), div(nat(1), nat(w + 3 * h)))
+    if not mixed:       # one mask for the three channels, like examples/chess.rs: the shapes belong to one tree
+        m = paint(tris)
+        return [mul(m, nat(255)), mul(max_(m, mul(grad, div(nat(1), nat(2)))), nat(255)), mul(add(mul(m, div(nat(3), nat(4))), mul(grad, div(nat(1), nat(4)))), nat(255))]
     return [mul(paint(tris), nat(255)), mul(max_(paint(tris[::2]), mul(grad, div(nat(1), nat(2)))), nat(255)),
             mul(add(mul(paint(tris[1::2] or tris), div(nat(3), nat(4))), mul(grad, div(nat(1), nat(4)))), nat(255))]
 
