@@ -439,6 +439,44 @@ struct RowBounds {
         return r;
     }
 
+    // For an arithmetic value v: an expression free of the coordinate with  zub == 0  =>  v is +0.0 (that very bit
+    // pattern) for every value of the coordinate in the span.  A boolean is its own witness; a product with a finite,
+    // sign-clear factor keeps it (+0 * c = +0); max, min and sum of sign-clear values combine their operands' (all
+    // operands +0 => +0).  c_true = no such statement.  `clear[i]`: the static analysis proves i NaN-free with its
+    // sign bit clear, `finite[i]`: and below +inf.
+    std::unordered_map<int32_t, int32_t> z_memo;
+    int32_t zub(int32_t i, const std::vector<uint8_t> &clear, const std::vector<uint8_t> &finite) {
+        if (i < 0 || (size_t)i >= isbool.size()) return c_true;
+        if (isbool[i]) return bounds(i).ub;
+        const DNode d = g.n[i];
+        if (!(d.dep & dep_bit) || d.a < 0 || d.b < 0 || !clear[i]) return c_true;
+        auto it = z_memo.find(i);
+        if (it != z_memo.end()) return it->second;
+        int32_t r = c_true;
+        const int32_t za = zub(d.a, clear, finite), zb = zub(d.b, clear, finite);
+        switch (d.op) {
+        case MARAY_OP_MUL: {
+            const bool by_a = za != c_true && clear[d.b] && finite[d.b], by_b = zb != c_true && clear[d.a] && finite[d.a];
+            if (by_a && by_b) r = g.binary(MARAY_OP_MIN, za, zb);
+            else if (by_a) r = za;
+            else if (by_b) r = zb;
+            break;
+        }
+        case MARAY_OP_MAX: case MARAY_OP_ADD:
+            if (za != c_true && zb != c_true && clear[d.a] && clear[d.b]) r = g.binary(MARAY_OP_MAX, za, zb);
+            break;
+        case MARAY_OP_MIN:
+            if (clear[d.a] && clear[d.b]) {
+                if (za != c_true && zb != c_true) r = g.binary(MARAY_OP_MIN, za, zb);
+                else r = za != c_true ? za : zb;
+            }
+            break;
+        default: break;
+        }
+        z_memo.emplace(i, r);
+        return r;
+    }
+
     B bounds(int32_t i) {
         if ((size_t)i >= isbool.size() || !isbool[i]) return {c_true, c_false, true};
         const DNode d = g.n[i];
@@ -500,12 +538,17 @@ struct Rebalancer {
             for (int32_t c : {g.n[i].a, g.n[i].b}) if (c >= 0) { users[c]++; st.push_back(c); }
         }
     }
-    int cls(int32_t i) const {                       // 1: OR, 2: AND of two booleans, 0: anything else
+    // 1: OR, 2: AND of two booleans; 3 / 4: max / min of anything else (NaN-ignoring max and min with +0 > -0 are
+    // associative and commutative as well: the result is the largest / smallest non-NaN operand whatever the order,
+    // a NaN only if all are); 0: anything else
+    int cls(int32_t i) const {
         if (i < 0 || (size_t)i >= isbool.size()) return 0;
         const DNode &d = g.n[i];
-        if (!isbool[i] || d.a < 0 || d.b < 0 || !isbool[d.a] || !isbool[d.b]) return 0;
-        if (d.op == MARAY_OP_MAX) return 1;
-        if (d.op == MARAY_OP_MUL || d.op == MARAY_OP_MIN) return 2;
+        if (d.a < 0 || d.b < 0) return 0;
+        const bool bools = isbool[i] && isbool[d.a] && isbool[d.b];
+        if (d.op == MARAY_OP_MAX) return bools ? 1 : 3;
+        if (d.op == MARAY_OP_MIN) return bools ? 2 : 4;
+        if (d.op == MARAY_OP_MUL && bools) return 2;
         return 0;
     }
     void leaves(int32_t i, int c, bool top, std::vector<int32_t> &out) {
@@ -530,7 +573,7 @@ struct Rebalancer {
         if (c) {
             std::vector<int32_t> l;
             leaves(i, c, true, l);
-            if (l.size() >= 4) { r = tree(l, 0, l.size(), c == 1 ? MARAY_OP_MAX : MARAY_OP_MIN); rebuilt++; done = true; }
+            if (l.size() >= 4) { r = tree(l, 0, l.size(), (c == 1 || c == 3) ? MARAY_OP_MAX : MARAY_OP_MIN); rebuilt++; done = true; }
         }
         if (!done && d.op < D_CONST) {
             const int32_t a = map(d.a), b = map(d.b);
@@ -1001,17 +1044,35 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         const std::vector<Mono> mono0 = monotonicity(g, iv0);
         RowBounds rb(g, isb0, mono0, iv0, DEP_X, D_X, D_XMIN, D_XMAX);
         rowub.assign(N0, -1);
-        std::vector<uint32_t> shapes(N0, 1);          // operands of the OR tree below a node
+        // sign bit provably clear and no NaN (so that "+0.0" statements compose), and finite on top
+        std::vector<uint8_t> clear(N0, 0), finite(N0, 0);
+        for (size_t i = 0; i < N0; i++) {
+            const DNode &d = g.n[i];
+            const bool ca = d.a >= 0 && clear[d.a], cb = d.b >= 0 && clear[d.b];
+            bool c = false;
+            switch (d.op) {
+            case D_CONST: c = d.cval == d.cval && !std::signbit(d.cval); break;
+            case D_X: case D_Y: case D_XMAX: case D_XMIN: case D_YMAX: case D_YMIN: c = true; break;
+            case MARAY_OP_STEP: case MARAY_OP_STEPSIN: case MARAY_OP_APP: case MARAY_OP_TEXDIM: c = true; break;
+            case MARAY_OP_ABS: c = !iv0[d.a].nan; break;                        // |-0| = +0
+            case MARAY_OP_SQRT: case MARAY_OP_MOV: c = ca; break;                // sqrt(+0) = +0
+            case MARAY_OP_ADD: case MARAY_OP_MUL: case MARAY_OP_MIN: case MARAY_OP_MAX: c = ca && cb; break;
+            default: break;
+            }
+            clear[i] = c && !iv0[i].nan;
+            finite[i] = clear[i] && iv0[i].hi < INFINITY;
+        }
+        std::vector<uint32_t> shapes(N0, 1);          // operands of the max tree below a node
         for (size_t i = 0; i < N0; i++) {
             const uint8_t op = g.n[i].op;
-            if (!isb0[i] || !(g.n[i].dep & DEP_X)) continue;
-            if (op == MARAY_OP_MAX && isb0[g.n[i].a] && isb0[g.n[i].b]) shapes[i] = shapes[g.n[i].a] + shapes[g.n[i].b];
-            // conjunctions, and ORs over a few shapes (two levels of a balanced tree: groups of 3-4 and of 9-16);
-            // an OR accumulating many shapes has a bound that is almost always true
+            if (!(g.n[i].dep & DEP_X) || g.n[i].a < 0 || g.n[i].b < 0) continue;
+            if (op == MARAY_OP_MAX) shapes[i] = shapes[g.n[i].a] + shapes[g.n[i].b];
+            // conjunctions (a shape), shapes times a colour, and max over a few shapes (two levels of a balanced tree:
+            // groups of 3-4 and of 9-16); a max accumulating many shapes has a bound that is almost always true
             const bool conj = op == MARAY_OP_MUL || op == MARAY_OP_MIN;
             const bool group = op == MARAY_OP_MAX && ((shapes[i] >= 3 && shapes[i] <= 4) || (shapes[i] >= 9 && shapes[i] <= 16));
             if (!conj && !group) continue;
-            const int32_t ub = rb.bounds((int32_t)i).ub;
+            const int32_t ub = isb0[i] ? rb.bounds((int32_t)i).ub : rb.zub((int32_t)i, clear, finite);
             if (g.n[ub].op < D_CONST) rowub[i] = ub;          // a real y-only op (not folded to a constant)
         }
         // Second pass, over y: a guard that is built from booleans monotone in y as well is bounded over the rows

@@ -98,6 +98,9 @@ def polygon_soup(seed, n, w, h, mixed=True):
             acc = max_(acc, t)
         return acc
     grad = mul(add(x(), mul(y(), nat(3))), div(nat(1), nat(w + 3 * h)))
+    if mixed == 'colours':      # every shape has its own colour: channel = max_i(shape_i * c_i), a max chain of non-booleans
+        cols = [[div(nat(rng.randrange(1, 9)), nat(8)) for _ in range(3)] for _ in tris]
+        return [mul(max_(paint([mul(t, c[k]) for t, c in zip(tris, cols)]), mul(grad, div(nat(1), nat(8)))), nat(255)) for k in range(3)]
     if not mixed:       # one mask for the three channels, like examples/chess.rs: the shapes belong to one tree
         m = paint(tris)
         return [mul(m, nat(255)), mul(max_(m, mul(grad, div(nat(1), nat(2)))), nat(255)), mul(add(mul(m, div(nat(3), nat(4))), mul(grad, div(nat(1), nat(4)))), nat(255))]

@@ -74,12 +74,12 @@ def test_polygon_soups_lowering_vs_oracle():
     group and shape guards, private regions -- evaluated with guards per row, per tile and per rectangle."""
     from fuzz_scenes import polygon_soup
     w, h = 256, 64
-    for seed in range(4):
-        data = encode((w, h), polygon_soup(seed, 24, w, h))
+    for seed, kind in ((0, True), (1, True), (2, False), (3, 'colours'), (4, 'colours')):
+        data = encode((w, h), polygon_soup(seed, 24, w, h, mixed=kind))
         tape = M.Scene(data).lower()
         assert tape.info['rebalanced_chains'] >= 3 and tape.info['private_regions'] >= 8
         n_guards, n_read_y = tape_eval.guards_reading_y(tape)
-        assert n_guards >= 6 and n_read_y == 0
+        assert n_guards >= (25 if kind == 'colours' else 6) and n_read_y == 0      # coloured shapes: guards on non-booleans too
         _, want64 = OScene(data).render_rows(w, h, 0, h)
         assert same_f64(tape_eval.render_rows(tape, w, 0, h), want64), seed
         assert same_f64(tape_eval.render_rows_waves(tape, w, 0, h), want64), seed
@@ -91,7 +91,7 @@ def test_polygon_soups_gpu_vs_oracle():
     from fuzz_scenes import polygon_soup
     w, h = 1024, 200
     for seed in range(10, 16):
-        data = encode((w, h), polygon_soup(seed, 70, w, h))
+        data = encode((w, h), polygon_soup(seed, 70, w, h, mixed=(True, False, 'colours')[seed % 3]))
         tape = M.Scene(data).lower()
         want8, want64 = OScene(data).render_rows(w, h, 0, h)
         for b in (M.BACKEND_JIT, M.BACKEND_TAPE, M.BACKEND_TAPE_SMEM):
