@@ -602,7 +602,7 @@ struct Privatizer {
     size_t budget;
 
     Privatizer(Dag &g_, std::vector<int32_t> &ub) : g(g_), rowub(ub), is_root(g_.n.size(), 0), seen(g_.n.size(), 0),
-                                                     remap(g_.n.size(), -2), budget(3 * g_.n.size() + 1024) {}
+                                                     remap(g_.n.size(), -2), budget(4 * g_.n.size() + 4096) {}
 
     bool x_op(int32_t i) const { return i >= 0 && g.n[i].op < D_CONST && (g.n[i].dep & DEP_X); }
 
@@ -639,14 +639,16 @@ struct Privatizer {
     }
     int32_t map(int32_t i) {
         if (i < 0 || (size_t)i >= remap.size()) return i;
-        if (remap[i] != -2) return remap[i];
-        int32_t r = i;
-        if (is_root[i]) {
+        if (is_root[i]) {                            // a copy per use: a shape two channels paint belongs to both their trees
             inst++; memo.clear();
-            r = clone(i);
+            const int32_t r = clone(i);
             rowub.resize(g.n.size(), -1);
             rowub[r] = rowub[i];
-        } else if (x_op(i)) {
+            return r;
+        }
+        if (remap[i] != -2) return remap[i];
+        int32_t r = i;
+        if (x_op(i)) {
             DNode d = g.n[i];
             const int32_t a = map(d.a), b = map(d.b);
             if (a != d.a || b != d.b) {
@@ -1059,7 +1061,7 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
             case MARAY_OP_ADD: case MARAY_OP_MUL: case MARAY_OP_MIN: case MARAY_OP_MAX: c = ca && cb; break;
             default: break;
             }
-            clear[i] = c && !iv0[i].nan;
+            clear[i] = isb0[i] || (c && !iv0[i].nan);      // a boolean is +0.0 or 1.0 whatever it is made of (1 + -(b) passes through -1)
             finite[i] = clear[i] && iv0[i].hi < INFINITY;
         }
         std::vector<uint32_t> shapes(N0, 1);          // operands of the max tree below a node

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/bench_soup.py [N] [mixed] — a scene of another kind than chess: N random textured triangles (tests/fuzz_scenes.py,
+"""tools/bench_soup.py [N] [mixed|colours] — a scene of another kind than chess: N random textured triangles (tests/fuzz_scenes.py,
 polygon_soup) at 4096 x 4096.  Build time, kernel time of both evaluators, parity of a band of rows with the oracle."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +13,8 @@ from test_lowering import same_f64
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 w = h = 4096
-mixed = len(sys.argv) > 2 and sys.argv[2] == 'mixed'      # mixed: every shape shared by two channels' OR trees
+mixed = {'mixed': True, 'colours': 'colours'}.get(sys.argv[2] if len(sys.argv) > 2 else '', False)   # mixed: shapes shared by two
+                                                            # channels' trees; colours: channel = max_i(shape_i * c_i)
 data = encode((w, h), fuzz_scenes.polygon_soup(1, n, w, h, mixed=mixed))
 t0 = time.time()
 tape = M.Scene(data).lower()
