@@ -5,7 +5,7 @@ import subprocess
 
 import scenes
 from conftest import GOLDEN, ROOT
-from fuzz_scenes import scene
+from fuzz_scenes import polygon_soup, scene
 from marayb import encode
 
 
@@ -27,7 +27,9 @@ def test_reader_and_lowering_under_asan_ubsan(tmp_path):
                            os.path.join(csrc, 'lower.cpp'), shim, '-o', exe])
     files = [os.path.join(GOLDEN, 'chess.maray')]
     for k, data in enumerate([encode((64, 64), scenes.all_ops(64, 64)), encode((64, 64), scenes.textured(64))] +
-                             [encode((83, 9), scene(seed, n_tex=2 if seed % 3 == 0 else 0)) for seed in range(40)]):
+                             [encode((83, 9), scene(seed, n_tex=2 if seed % 3 == 0 else 0)) for seed in range(40)] +
+                             [encode((512, 128), polygon_soup(7, 40, 512, 128, mixed=kind)) for kind in (True, False, 'colours')] +
+                             [encode((192, 24), scenes.shapes_through_inf_and_nan())]):
         p = str(tmp_path / ('s%d.maray' % k))
         open(p, 'wb').write(data)
         files.append(p)
