@@ -72,6 +72,10 @@ int maray_scene_fix_color(maray_scene *s);
  * scene including Let definitions: X -> X * (1/sx), Y -> Y * (1/sy), and the
  * header size multiplied by (sx, sy).  Exact when sx, sy are powers of two. */
 int maray_scene_rescale(maray_scene *s, uint32_t sx, uint32_t sy);
+/* `Expr::simplify` on each channel (src/lib.rs:601-604: constant_reduction at the root, src/constant_reduction.rs:9-185,
+ * then the rewrite rules of src/simplify.rs:129-327).  Authoring-time, not on the render path; the reference applies it
+ * before `save` (examples/chess.rs:43).  `compress` is not provided. */
+int maray_scene_simplify(maray_scene *s);
 
 /* ---- lowering: Expr -> tape ---------------------------------------------------
  * Replaces what the reference does per pixel in `Expr::eval2` + `Cache`

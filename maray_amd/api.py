@@ -89,6 +89,7 @@ def lib():
         'maray_scene_save': (C.c_int, [vp, C.c_char_p]),
         'maray_scene_fix_color': (C.c_int, [vp]),
         'maray_scene_rescale': (C.c_int, [vp, u32, u32]),
+        'maray_scene_simplify': (C.c_int, [vp]),
         'maray_lower': (C.c_int, [vp, C.POINTER(LowerOpts), C.POINTER(vp)]),
         'maray_tape_free': (None, [vp]),
         'maray_tape_program': (C.c_int, [vp, C.POINTER(Program)]),
@@ -198,6 +199,10 @@ class Scene:
 
     def fix_color(self):
         _check(lib().maray_scene_fix_color(self._h))
+
+    def simplify(self):
+        """Expr::simplify on each channel (authoring-time rewrite rules of the reference)."""
+        _check(lib().maray_scene_simplify(self._h))
 
     def rescale(self, sx, sy):
         _check(lib().maray_scene_rescale(self._h, sx, sy))

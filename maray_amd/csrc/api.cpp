@@ -247,6 +247,11 @@ int maray_scene_rescale(maray_scene *s, uint32_t sx, uint32_t sy)
     return guard([&] { REQUIRE(s, "null argument"); scene_rescale(s->s, sx, sy); });
 }
 
+int maray_scene_simplify(maray_scene *s)
+{
+    return guard([&] { REQUIRE(s, "null argument"); run_big_stack([&] { scene_simplify(s->s); }); });
+}
+
 // ---- lowering -----------------------------------------------------------------
 int maray_lower(const maray_scene *s, const maray_lower_opts *opts, maray_tape **out)
 {

@@ -67,5 +67,7 @@ void scene_encode(const Scene &s, std::vector<uint8_t> &out);            // curr
 uint64_t scene_node_count(const Scene &s, int c);
 void scene_fix_color(Scene &s);                                          // var_fixer::fix_color
 void scene_rescale(Scene &s, uint32_t sx, uint32_t sy);
+// simplify.cpp
+void scene_simplify(Scene &s);                                           // Expr::simplify on each channel
 
 }   // namespace maray
