@@ -208,8 +208,10 @@ struct Simp {
     // and so on for ever unless a is a natural (the reference overflows its stack on such input; examples/chess.rs
     // does not produce it).  Here that is an error, not a crash.
     int depth = 0;
+    bool runaway = false;                  // reported by scene_simplify once the recursion has unwound by itself
     int32_t simplify(int32_t e) {
-        if (++depth > 200000) throw Error{MARAY_E_LIMIT, "simplify: the rewrite rules do not terminate on this expression (src/simplify.rs:276-283 keeps swapping the divisors of (a/b)/c)"};
+        if (runaway) return e;
+        if (++depth > 50000) { runaway = true; depth--; return e; }
         const int32_t r = run(constant_reduction(e));
         depth--;
         return r;
@@ -350,7 +352,11 @@ struct Simp {
 void scene_simplify(Scene &s)
 {
     Simp z(s);
-    for (int c = 0; c < 3; c++) s.color[c] = z.simplify(s.color[c]);
+    int32_t out[3];
+    for (int c = 0; c < 3; c++) out[c] = z.simplify(s.color[c]);
+    if (z.runaway)
+        throw Error{MARAY_E_LIMIT, "simplify: the rewrite rules do not terminate on this expression (src/simplify.rs:276-283 keeps swapping the divisors of (a/b)/c)"};
+    for (int c = 0; c < 3; c++) s.color[c] = out[c];
 }
 
 }   // namespace maray

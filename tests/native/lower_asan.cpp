@@ -1,7 +1,9 @@
-// lower_asan.cpp — host-only sanitizer harness for the product's reader, fix_color and lowering
+// lower_asan.cpp — host-only sanitizer harness for the product's reader, fix_color, simplify and lowering
 // (test infrastructure).  Built with -fsanitize=address,undefined together with scene.cpp and lower.cpp;
 // reads .maray files given on the command line, lowers each with several option sets and validates the
 // resulting programs structurally.
+#include <pthread.h>
+
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -26,7 +28,25 @@ static std::vector<uint8_t> slurp(const char *path)
     return b;
 }
 
+static int g_argc; static char **g_argv; static int g_rc;
+static int real_main(int argc, char **argv);
+static void *big_stack(void *) { g_rc = real_main(g_argc, g_argv); return nullptr; }
+
+// everything runs on a thread with a large stack, like the library's own entry points (the reader, the simplifier and
+// the lowering recurse over trees)
 int main(int argc, char **argv)
+{
+    g_argc = argc; g_argv = argv;
+    pthread_attr_t at;
+    pthread_attr_init(&at);
+    pthread_attr_setstacksize(&at, (size_t)1 << 30);
+    pthread_t th;
+    if (pthread_create(&th, &at, big_stack, nullptr) != 0) return 2;
+    pthread_join(th, nullptr);
+    return g_rc;
+}
+
+static int real_main(int argc, char **argv)
 {
     int lowered = 0, rejected = 0;
     for (int i = 1; i < argc; i++) {
@@ -39,6 +59,11 @@ int main(int argc, char **argv)
             catch (const Error &) { rejected++; continue; }
             std::vector<uint8_t> again;
             scene_encode(s, again);
+            if (bytes.size() < (1u << 20)) {            // the authoring-time simplifier on a copy (small scenes: it is recursive)
+                Scene c = s;
+                try { scene_simplify(c); scene_encode(c, again); }
+                catch (const Error &e) { if (e.code != MARAY_E_LIMIT) { fprintf(stderr, "%s: simplify: %s\n", argv[i], e.msg.c_str()); return 1; } }
+            }
             for (int variant = 0; variant < 4; variant++) {
                 maray_lower_opts o;
                 memset(&o, 0, sizeof o);
