@@ -53,6 +53,8 @@ struct KArgs {
     // guard guard_first + g.  PIXEL reads them instead of y values; the GUARDS kernel (job j = 8 guards = one byte,
     // tape[job_off[j] .. + job_len[j])) writes them.
     uint32_t *gbits;
+    const uint64_t *xtape;     // PIXEL: the section pre-decoded for run_xtape, or null (generic loop)
+    uint32_t x_slot;           // run_xtape: slots x_slot, x_slot + 1, x_slot + 2 hold X, Y and the results nothing reads
     const uint32_t *job_off, *job_len;
     uint32_t guard_first, guard_w32, guard_rows;
 };
@@ -177,6 +179,124 @@ __device__ __forceinline__ void run_tape(const KArgs &A, const uint64_t *tape_g,
     }
 }
 
+
+// ---- PIXEL section, pre-decoded ("xtape") --------------------------------------------------------
+// The generic loop above spends ~20 scalar branches per op finding out what its operands are (kind of a, kind of b,
+// which special, LDS or spill, dst or none): every condition is wave-uniform, so each is a real branch, and branches
+// -- not arithmetic -- are what an op costs.  For the PIXEL section the host rewrites each op once into a word
+// whose opcode already says where the operands live, and the loop is one jump table:
+//   operand classes  S: value slot in LDS (X and Y of the pixel are parked in two reserved slots per tile)
+//                    A: ACC          U: wave-uniform table, index < n_consts -> constant, else y value
+//   dst: a slot, or the reserved trash slot (no "if (dst != none)")
+// Same layout as a tape word (op 7 | aux 13 | dst 12 | a 16 | b 16).  Programs whose slots do not fit LDS keep the
+// generic loop.
+enum {
+    XS = 0, XA = 1, XU = 2,                       // operand classes
+    XG = 3,                                       // SKIP guard: a bit of the rectangle's guard words
+    X_NOP = 0,
+    X_BIN = 16,                                   // + 9 * {ADD, MUL, MAX, MIN} + 3 * class(a) + class(b)
+    X_UN = 52,                                    // + 3 * {NEG, ABS, STEP, MOV} + class(a)
+    X_HEAVY = 64,                                 // + {RECIP, SQRT, SIN, STEPSIN, EXP, LN}; class(a) in the b field
+    X_APP = 72,                                   // + 3 * class(a) + class(b)
+    X_TEXDIM = 81,
+    X_OUT = 82,                                   // + class(a)
+    X_SKIPZ = 85, X_SKIPNZ = 89,                  // + class(guard) (XS, XA, XU = a y value bounded over the row, XG)
+};
+
+template <bool TAPE_LDS>
+__device__ __forceinline__ void run_xtape(const KArgs &A, const uint64_t *tape_lds, const double *consts_lds, double *slots,
+                                          const Item &I, double &o0, double &o1, double &o2)
+{
+    const uint32_t tid = threadIdx.x;
+    double acc = 0.0;
+    k_u64_ptr tape_k = (k_u64_ptr)A.xtape;
+    k_f64_ptr consts_k = (k_f64_ptr)A.consts;
+    k_f64_ptr yrow_k = (k_f64_ptr)I.yrow;
+    const __attribute__((address_space(4))) uint32_t *gk_k = (const __attribute__((address_space(4))) uint32_t *)I.gk;
+    const uint32_t nc = A.n_consts;
+#define FS(i) slots[(i) * BLOCK + tid]
+    auto FU = [&](uint32_t i) -> double {          // both tables are read, the index picks: no branch
+        const double c = TAPE_LDS ? consts_lds[i < nc ? i : 0u] : consts_k[i < nc ? i : 0u];
+        const double y = yrow_k[i < nc ? 0u : i - nc];
+        return i < nc ? c : y;
+    };
+    auto FG = [&](uint32_t k, uint32_t i) -> double { return k == XS ? FS(i) : (k == XA ? acc : FU(i)); };   // heavy ops only
+    for (uint32_t pc = 0; pc < A.n_ops; ++pc) {
+        uint32_t lo, hi;
+        if (TAPE_LDS) {
+            const uint64_t ins = tape_lds[pc];
+            lo = uni((uint32_t)ins); hi = uni((uint32_t)(ins >> 32));
+        } else {
+            const uint64_t ins = tape_k[pc];
+            lo = uni((uint32_t)ins); hi = uni((uint32_t)(ins >> 32));
+        }
+        const uint32_t op = lo & 0x7Fu, aux = (lo >> 7) & 0x1FFFu, dst = lo >> 20;
+        const uint32_t ia = hi & 0xFFFFu, ib = hi >> 16;
+        double r;
+#define BIN9(BASE, EXPR)                                                                            \
+        case BASE + 0: { const double a = FS(ia), b = FS(ib); r = EXPR; break; }                    \
+        case BASE + 1: { const double a = FS(ia), b = acc; r = EXPR; break; }                       \
+        case BASE + 2: { const double a = FS(ia), b = FU(ib); r = EXPR; break; }                    \
+        case BASE + 3: { const double a = acc, b = FS(ib); r = EXPR; break; }                       \
+        case BASE + 4: { const double a = acc, b = acc; r = EXPR; break; }                          \
+        case BASE + 5: { const double a = acc, b = FU(ib); r = EXPR; break; }                       \
+        case BASE + 6: { const double a = FU(ia), b = FS(ib); r = EXPR; break; }                    \
+        case BASE + 7: { const double a = FU(ia), b = acc; r = EXPR; break; }                       \
+        case BASE + 8: { const double a = FU(ia), b = FU(ib); r = EXPR; break; }
+#define UN3(BASE, EXPR)                                                                             \
+        case BASE + 0: { const double a = FS(ia); r = EXPR; break; }                                \
+        case BASE + 1: { const double a = acc; r = EXPR; break; }                                   \
+        case BASE + 2: { const double a = FU(ia); r = EXPR; break; }
+        switch (op) {
+        BIN9(X_BIN + 0, a + b)
+        BIN9(X_BIN + 9, a * b)
+        BIN9(X_BIN + 18, mr_max(a, b))
+        BIN9(X_BIN + 27, mr_min(a, b))
+        UN3(X_UN + 0, mr_neg(a))
+        UN3(X_UN + 3, mr_abs(a))
+        UN3(X_UN + 6, mr_step(a))
+        UN3(X_UN + 9, a)
+        case X_HEAVY + 0: r = mr_recip(FG(ib, ia)); break;
+        case X_HEAVY + 1: r = mr_sqrt(FG(ib, ia)); break;
+        case X_HEAVY + 2: r = mr_sin(FG(ib, ia)); break;
+        case X_HEAVY + 3: r = mr_stepsin(FG(ib, ia)); break;
+        case X_HEAVY + 4: r = mr_exp(FG(ib, ia)); break;
+        case X_HEAVY + 5: r = mr_ln(FG(ib, ia)); break;
+        BIN9(X_APP, mr_app(A.tex, aux, a, b))
+        case X_TEXDIM: r = mr_texdim(A.tex, aux); break;
+        case X_OUT + 0: case X_OUT + 1: case X_OUT + 2: {
+            const double v = FG(op - X_OUT, ia);
+            if (aux == 0) o0 = v; else if (aux == 1) o1 = v; else o2 = v;
+            continue;                                     // OUT leaves ACC and slots untouched
+        }
+        case X_SKIPZ + XS: case X_SKIPZ + XA: case X_SKIPZ + XU: case X_SKIPZ + XG:
+        case X_SKIPNZ + XS: case X_SKIPNZ + XA: case X_SKIPNZ + XU: case X_SKIPNZ + XG: {
+            const bool nz = op >= X_SKIPNZ;
+            const uint32_t k = op - (nz ? X_SKIPNZ : X_SKIPZ);
+            bool decided;
+            if (k == XG) decided = ((gk_k[ia >> 5] >> (ia & 31u)) & 1u) == (nz ? 1u : 0u);       // one bit, wave-uniform
+            else if (k == XU) decided = FU(ia) == (nz ? 1.0 : 0.0);                                // a y value: uniform
+            else {
+                const double gv = k == XS ? FS(ia) : acc;
+                decided = nz ? (__builtin_amdgcn_ballot_w64(gv != 1.0) == 0ull) : (__builtin_amdgcn_ballot_w64(gv != 0.0) == 0ull);
+            }
+            if (decided) {
+                acc = nz ? 1.0 : 0.0;
+                FS(dst) = acc;
+                pc += aux;
+            }
+            continue;
+        }
+        default: continue;                                // NOP
+        }
+#undef BIN9
+#undef UN3
+        acc = r;
+        FS(dst) = r;
+    }
+#undef FS
+}
+
 // PIXEL kernel.  Block = 256 consecutive pixels of one row ("tile"); blocks
 // stride over tiles so the LDS staging of the tape is paid once per block.
 template <bool TAPE_LDS>
@@ -189,7 +309,8 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_pixels(const KArgs A)
     if (TAPE_LDS) {
         uint64_t *tl = (uint64_t *)smem;
         double *cl = (double *)(smem + (size_t)A.n_ops * 8);
-        for (uint32_t i = threadIdx.x; i < A.n_ops; i += BLOCK) tl[i] = A.tape[i];
+        const uint64_t *src = A.xtape ? A.xtape : A.tape;
+        for (uint32_t i = threadIdx.x; i < A.n_ops; i += BLOCK) tl[i] = src[i];
         for (uint32_t i = threadIdx.x; i < A.n_consts; i += BLOCK) cl[i] = A.consts[i];
         tape_lds = tl; consts_lds = cl;
         slots = (double *)(smem + ((size_t)A.n_ops + A.n_consts) * 8);
@@ -212,7 +333,12 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_pixels(const KArgs A)
         I.yrow = A.yvals + (size_t)r * A.n_yvals;
         I.gk = A.guard_w32 ? A.gbits + ((size_t)(r / A.guard_rows) * A.tiles_per_row + (tile - r * A.tiles_per_row)) * A.guard_w32 : nullptr;
         I.X = (double)x; I.Y = (double)y;                                            // p = [x as f64, y as f64]
-        run_tape<TAPE_LDS, MODE_PIXEL>(A, A.tape, A.n_ops, tape_lds, consts_lds, slots, spill_base, spill_stride, I, o0, o1, o2, unused);
+        if (A.xtape) {
+            slots[A.x_slot * BLOCK + threadIdx.x] = I.X;
+            slots[(A.x_slot + 1) * BLOCK + threadIdx.x] = I.Y;
+            run_xtape<TAPE_LDS>(A, tape_lds, consts_lds, slots, I, o0, o1, o2);
+        } else
+            run_tape<TAPE_LDS, MODE_PIXEL>(A, A.tape, A.n_ops, tape_lds, consts_lds, slots, spill_base, spill_stride, I, o0, o1, o2, unused);
         if (x < A.w) {
             const size_t p = ((size_t)r * A.w + x) * 3;
             if (A.rgb64) { A.rgb64[p] = o0; A.rgb64[p + 1] = o1; A.rgb64[p + 2] = o2; }
@@ -283,6 +409,59 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_guards(const KArgs A)
             throw Error{MARAY_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)};           \
     } while (0)
 
+// PIXEL section -> xtape (see run_xtape).  guard_first: y values from this index on are read as guard bits by SKIP ops
+// (0xFFFFFFFF: none are).
+std::vector<uint64_t> predecode_pixels(const maray_program &P, uint32_t x_slot, uint32_t guard_first)
+{
+    std::vector<uint64_t> out(P.n_pix_ops, 0);
+    auto operand = [&](uint32_t ref, uint32_t &k, uint32_t &idx) {
+        const uint32_t kind = MARAY_REF_KIND(ref), i = MARAY_REF_INDEX(ref);
+        if (kind == MARAY_K_SLOT) { k = XS; idx = i; }
+        else if (kind == MARAY_K_CONST) { k = XU; idx = i; }
+        else if (kind == MARAY_K_YVAL) { k = XU; idx = P.n_consts + i; }
+        else if (i == MARAY_SPEC_ACC) { k = XA; idx = 0; }
+        else { k = XS; idx = x_slot + (i == MARAY_SPEC_X ? 0u : 1u); }      // the validator admits only X, Y, ACC here
+    };
+    for (uint32_t j = 0; j < P.n_pix_ops; j++) {
+        const uint64_t ins = P.pix_ops[j];
+        const uint32_t op = MARAY_INS_OP(ins), aux = MARAY_INS_AUX(ins);
+        uint32_t dst = MARAY_INS_DST(ins);
+        if (dst == MARAY_DST_NONE) dst = x_slot + 2;
+        uint32_t ka = 0, ia = 0, kb = 0, ib = 0, x = X_NOP;
+        if (op != MARAY_OP_NOP && op != MARAY_OP_TEXDIM) operand(MARAY_INS_A(ins), ka, ia);
+        if (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) operand(MARAY_INS_B(ins), kb, ib);
+        switch (op) {
+        case MARAY_OP_NOP: break;
+        case MARAY_OP_ADD: x = X_BIN + 0 + 3 * ka + kb; break;
+        case MARAY_OP_MUL: x = X_BIN + 9 + 3 * ka + kb; break;
+        case MARAY_OP_MAX: x = X_BIN + 18 + 3 * ka + kb; break;
+        case MARAY_OP_MIN: x = X_BIN + 27 + 3 * ka + kb; break;
+        case MARAY_OP_NEG: x = X_UN + 0 + ka; break;
+        case MARAY_OP_ABS: x = X_UN + 3 + ka; break;
+        case MARAY_OP_STEP: x = X_UN + 6 + ka; break;
+        case MARAY_OP_MOV: x = X_UN + 9 + ka; break;
+        case MARAY_OP_RECIP: x = X_HEAVY + 0; ib = ka; break;
+        case MARAY_OP_SQRT: x = X_HEAVY + 1; ib = ka; break;
+        case MARAY_OP_SIN: x = X_HEAVY + 2; ib = ka; break;
+        case MARAY_OP_STEPSIN: x = X_HEAVY + 3; ib = ka; break;
+        case MARAY_OP_EXP: x = X_HEAVY + 4; ib = ka; break;
+        case MARAY_OP_LN: x = X_HEAVY + 5; ib = ka; break;
+        case MARAY_OP_APP: x = X_APP + 3 * ka + kb; break;
+        case MARAY_OP_TEXDIM: x = X_TEXDIM; break;
+        case MARAY_OP_OUT: x = X_OUT + ka; dst = 0; break;
+        case MARAY_OP_SKIPZ: case MARAY_OP_SKIPNZ: {
+            const uint32_t ref = MARAY_INS_A(ins);
+            if (MARAY_REF_KIND(ref) == MARAY_K_YVAL && MARAY_REF_INDEX(ref) >= guard_first) { ka = XG; ia = MARAY_REF_INDEX(ref) - guard_first; }
+            x = (op == MARAY_OP_SKIPZ ? X_SKIPZ : X_SKIPNZ) + ka;
+            break;
+        }
+        default: break;
+        }
+        out[j] = MARAY_INS(x, aux, dst, ia, ib);
+    }
+    return out;
+}
+
 struct TapeBackend final : Backend {
     int device = 0;
     bool tape_lds = true;
@@ -304,6 +483,9 @@ struct TapeBackend final : Backend {
     uint64_t *d_guard_ops = nullptr;
     uint32_t *d_job_off = nullptr, *d_job_len = nullptr;
     uint32_t *d_gbits = nullptr; size_t gbits_cap = 0;
+    // PIXEL section pre-decoded for run_xtape: one variant reads guards as bits, one as y values (the drain)
+    uint64_t *d_xtape_bits = nullptr, *d_xtape_rows = nullptr;
+    uint32_t x_slot = 0;
     unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;
     double *d_rgb64 = nullptr; size_t rgb64_cap = 0;
     hipStream_t own_stream = nullptr;
@@ -318,6 +500,7 @@ struct TapeBackend final : Backend {
         for (auto p : d_tex_rgb) (void)hipFree(p);
         (void)hipFree(d_yvals); (void)hipFree(d_spill); (void)hipFree(d_rgb8); (void)hipFree(d_rgb64);
         (void)hipFree(d_guard_ops); (void)hipFree(d_job_off); (void)hipFree(d_job_len); (void)hipFree(d_gbits);
+        (void)hipFree(d_xtape_bits); (void)hipFree(d_xtape_rows);
         if (own_stream) (void)hipStreamDestroy(own_stream);
     }
 
@@ -394,6 +577,19 @@ struct TapeBackend final : Backend {
         guard_lds_slots = (uint32_t)std::min<size_t>(guard_slots, 40);       // 80 KB: two blocks per CU; the rest spills
         guard_lds_bytes = (uint32_t)(guard_lds_slots * slot_bytes);
         if (tile_guards) HIP_TRY(hipFuncSetAttribute((const void *)maray_tape_guards, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+        // the pre-decoded loop needs every slot in LDS plus three (X, Y, trash)
+        if (base + ((size_t)prog.n_pix_slots + 3) * slot_bytes <= lds_cap && prog.n_pix_slots + 3 < MARAY_DST_NONE && !getenv("MARAY_TAPE_GENERIC")) {
+            x_slot = prog.n_pix_slots;
+            n_lds_slots = prog.n_pix_slots + 3;
+            lds_bytes = (uint32_t)(base + (size_t)n_lds_slots * slot_bytes);
+            blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, lds_cap / std::max<uint32_t>(lds_bytes, 1)));
+            const std::vector<uint64_t> xr = predecode_pixels(prog, x_slot, 0xFFFFFFFFu);
+            up(xr.data(), xr.size() * 8, (void **)&d_xtape_rows);
+            if (tile_guards) {
+                const std::vector<uint64_t> xb = predecode_pixels(prog, x_slot, n_ynum);
+                up(xb.data(), xb.size() * 8, (void **)&d_xtape_bits);
+            }
+        }
         if (lds_variant) {
             HIP_TRY(hipFuncSetAttribute((const void *)maray_tape_pixels<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
             kname = "maray_tape_pixels<true>";
@@ -472,6 +668,8 @@ struct TapeBackend final : Backend {
         A.w = w; A.y0 = y0; A.rows = rows; A.blk_rows = rb.block_rows; A.blk_stride = rb.block_stride;
         A.tiles_per_row = tiles_per_row;
         if (bits) { A.gbits = d_gbits; A.guard_first = n_ynum; A.guard_w32 = n_guard_w32; A.guard_rows = guard_rows; }
+        A.xtape = bits ? d_xtape_bits : d_xtape_rows;
+        A.x_slot = x_slot;
         const uint64_t tiles = (uint64_t)A.tiles_per_row * rows;
         if (tiles > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
         A.n_tiles = (uint32_t)tiles;
