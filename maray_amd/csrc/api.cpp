@@ -421,7 +421,7 @@ int maray_row_cone(const maray_program *prog, uint32_t first_out, uint32_t n_out
             if (k >= first_out && k - first_out < n_out) outs.push_back(o);
         }
         std::vector<uint64_t> t = compact_tape(row_tape_cone(*prog, deps, outs, nullptr));
-        *n_slots_out = renumber_slots(t);
+        *n_slots_out = getenv("MARAY_TAPE_KEEP_ORDER") ? renumber_slots(t) : reschedule_tape(t);
         *n_ops_out = (uint32_t)t.size();
         *ops_out = (uint64_t *)malloc(t.size() * 8 + 8);
         if (!*ops_out) throw Error{MARAY_E_INTERNAL, "out of memory"};

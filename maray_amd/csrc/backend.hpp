@@ -60,6 +60,7 @@ std::vector<uint64_t> row_tape_cone(const maray_program &P, const RowTapeDeps &d
 std::vector<uint64_t> compact_tape(const std::vector<uint64_t> &tape);
 // Renumbers the value slots of a compacted tape by liveness; returns the number of slots it then uses.
 uint32_t renumber_slots(std::vector<uint64_t> &tape);
+uint32_t reschedule_tape(std::vector<uint64_t> &tape);   // cone re-ordered depth first + slots by liveness
 // Does any guard (a y value that only gates SKIP ops) have SPEC Y in its cone?  If none does, guards may be evaluated
 // once for a group of rows (YMIN / YMAX, include/maray_tape.h).
 bool any_guard_reads_y(const maray_program &P);

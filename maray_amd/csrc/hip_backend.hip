@@ -185,7 +185,8 @@ __device__ __forceinline__ void run_tape(const KArgs &A, const uint64_t *tape_g,
 // which special, LDS or spill, dst or none): every condition is wave-uniform, so each is a real branch, and branches
 // -- not arithmetic -- are what an op costs.  For the PIXEL section the host rewrites each op once into a word
 // whose opcode already says where the operands live, and the loop is one jump table:
-//   operand classes  S: value slot in LDS (X and Y of the pixel are parked in two reserved slots per tile)
+//   operand classes  S: value slot in LDS (the item's X, Y -- and in the ROW sections its span XMIN .. YMAX -- are parked
+//                       in reserved slots: x_slot + 0 X, 1 Y, 2 trash, 3 XMIN, 4 XMAX, 5 YMIN, 6 YMAX)
 //                    A: ACC          U: wave-uniform table, index < n_consts -> constant, else y value
 //   dst: a slot, or the reserved trash slot (no "if (dst != none)")
 // Same layout as a tape word (op 7 | aux 13 | dst 12 | a 16 | b 16).  Programs whose slots do not fit LDS keep the
@@ -203,13 +204,13 @@ enum {
     X_SKIPZ = 85, X_SKIPNZ = 89,                  // + class(guard) (XS, XA, XU = a y value bounded over the row, XG)
 };
 
-template <bool TAPE_LDS>
-__device__ __forceinline__ void run_xtape(const KArgs &A, const uint64_t *tape_lds, const double *consts_lds, double *slots,
-                                          const Item &I, double &o0, double &o1, double &o2)
+template <bool TAPE_LDS, int MODE>
+__device__ __forceinline__ void run_xtape(const KArgs &A, const uint64_t *xtape, uint32_t n_ops, const uint64_t *tape_lds, const double *consts_lds,
+                                          double *slots, const Item &I, double &o0, double &o1, double &o2, uint32_t &gacc)
 {
     const uint32_t tid = threadIdx.x;
     double acc = 0.0;
-    k_u64_ptr tape_k = (k_u64_ptr)A.xtape;
+    k_u64_ptr tape_k = (k_u64_ptr)xtape;
     k_f64_ptr consts_k = (k_f64_ptr)A.consts;
     k_f64_ptr yrow_k = (k_f64_ptr)I.yrow;
     const __attribute__((address_space(4))) uint32_t *gk_k = (const __attribute__((address_space(4))) uint32_t *)I.gk;
@@ -221,11 +222,18 @@ __device__ __forceinline__ void run_xtape(const KArgs &A, const uint64_t *tape_l
         return i < nc ? c : y;
     };
     auto FG = [&](uint32_t k, uint32_t i) -> double { return k == XS ? FS(i) : (k == XA ? acc : FU(i)); };   // heavy ops only
-    for (uint32_t pc = 0; pc < A.n_ops; ++pc) {
+    // the ROW kernels run a few wavefronts per CU (their slots fill the LDS): nothing hides the scalar load of the next
+    // word, so it is issued one op ahead (the PIXEL kernel has the occupancy and gains nothing from it)
+    constexpr bool AHEAD = !TAPE_LDS && MODE != MODE_PIXEL;
+    uint64_t ahead = (AHEAD && n_ops) ? tape_k[0] : 0;
+    for (uint32_t pc = 0; pc < n_ops; ++pc) {
         uint32_t lo, hi;
         if (TAPE_LDS) {
             const uint64_t ins = tape_lds[pc];
             lo = uni((uint32_t)ins); hi = uni((uint32_t)(ins >> 32));
+        } else if (AHEAD) {
+            lo = uni((uint32_t)ahead); hi = uni((uint32_t)(ahead >> 32));
+            ahead = tape_k[pc + 1 < n_ops ? pc + 1 : pc];
         } else {
             const uint64_t ins = tape_k[pc];
             lo = uni((uint32_t)ins); hi = uni((uint32_t)(ins >> 32));
@@ -266,7 +274,9 @@ __device__ __forceinline__ void run_xtape(const KArgs &A, const uint64_t *tape_l
         case X_TEXDIM: r = mr_texdim(A.tex, aux); break;
         case X_OUT + 0: case X_OUT + 1: case X_OUT + 2: {
             const double v = FG(op - X_OUT, ia);
-            if (aux == 0) o0 = v; else if (aux == 1) o1 = v; else o2 = v;
+            if (MODE == MODE_ROW) I.yout[aux] = v;
+            else if (MODE == MODE_GUARDS) { if (v != 0.0) gacc |= 1u << ((aux - A.guard_first) & 7u); }
+            else if (aux == 0) o0 = v; else if (aux == 1) o1 = v; else o2 = v;
             continue;                                     // OUT leaves ACC and slots untouched
         }
         case X_SKIPZ + XS: case X_SKIPZ + XA: case X_SKIPZ + XU: case X_SKIPZ + XG:
@@ -274,7 +284,7 @@ __device__ __forceinline__ void run_xtape(const KArgs &A, const uint64_t *tape_l
             const bool nz = op >= X_SKIPNZ;
             const uint32_t k = op - (nz ? X_SKIPNZ : X_SKIPZ);
             bool decided;
-            if (k == XG) decided = ((gk_k[ia >> 5] >> (ia & 31u)) & 1u) == (nz ? 1u : 0u);       // one bit, wave-uniform
+            if (k == XG) decided = MODE == MODE_PIXEL && ((gk_k[ia >> 5] >> (ia & 31u)) & 1u) == (nz ? 1u : 0u);       // one bit, wave-uniform
             else if (k == XU) decided = FU(ia) == (nz ? 1.0 : 0.0);                                // a y value: uniform
             else {
                 const double gv = k == XS ? FS(ia) : acc;
@@ -284,6 +294,7 @@ __device__ __forceinline__ void run_xtape(const KArgs &A, const uint64_t *tape_l
                 acc = nz ? 1.0 : 0.0;
                 FS(dst) = acc;
                 pc += aux;
+                if (AHEAD) ahead = tape_k[pc + 1 < n_ops ? pc + 1 : pc];
             }
             continue;
         }
@@ -295,6 +306,14 @@ __device__ __forceinline__ void run_xtape(const KArgs &A, const uint64_t *tape_l
         FS(dst) = r;
     }
 #undef FS
+}
+
+__device__ __forceinline__ void park_specials(const KArgs &A, double *slots, const Item &I)
+{
+    const uint32_t t = threadIdx.x, b = A.x_slot;
+    slots[(b + 1) * BLOCK + t] = I.Y;
+    slots[(b + 3) * BLOCK + t] = I.xmin; slots[(b + 4) * BLOCK + t] = I.xmax;
+    slots[(b + 5) * BLOCK + t] = I.ymin; slots[(b + 6) * BLOCK + t] = I.ymax;
 }
 
 // PIXEL kernel.  Block = 256 consecutive pixels of one row ("tile"); blocks
@@ -336,7 +355,7 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_pixels(const KArgs A)
         if (A.xtape) {
             slots[A.x_slot * BLOCK + threadIdx.x] = I.X;
             slots[(A.x_slot + 1) * BLOCK + threadIdx.x] = I.Y;
-            run_xtape<TAPE_LDS>(A, tape_lds, consts_lds, slots, I, o0, o1, o2);
+            run_xtape<TAPE_LDS, MODE_PIXEL>(A, A.xtape, A.n_ops, tape_lds, consts_lds, slots, I, o0, o1, o2, unused);
         } else
             run_tape<TAPE_LDS, MODE_PIXEL>(A, A.tape, A.n_ops, tape_lds, consts_lds, slots, spill_base, spill_stride, I, o0, o1, o2, unused);
         if (x < A.w) {
@@ -360,15 +379,26 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_rows(const KArgs A)
     double *slots = (double *)smem;
     const uint32_t spill_stride = gridDim.x * BLOCK;
     double *spill_base = A.spill ? A.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
-    const uint32_t r = blockIdx.x * BLOCK + threadIdx.x;
-    const uint32_t rr = r < A.rows ? r : A.rows - 1;               // keep the wave uniform; surplus lanes recompute the last row
-    double o0, o1, o2;
-    uint32_t unused = 0;
-    Item I{};
-    I.Y = (double)(A.y0 + (rr / A.blk_rows) * A.blk_stride + rr % A.blk_rows);
-    I.xmin = 0.0; I.xmax = (double)(A.w - 1u); I.ymin = I.Y; I.ymax = I.Y;
-    I.yout = A.yout + (size_t)rr * A.n_yvals;
-    run_tape<false, MODE_ROW>(A, A.tape, A.n_ops, nullptr, nullptr, slots, spill_base, spill_stride, I, o0, o1, o2, unused);
+    const uint32_t row_blocks = (A.rows + BLOCK - 1) / BLOCK;
+    // the section is cut into jobs (the cone of 8 y values each: dozens of ops, not the section's thousands in one
+    // dependent chain); blocks stride over (job, block of rows) pairs, so the grid and the spill area stay bounded
+    for (uint32_t u = blockIdx.x; u < row_blocks * A.n_tiles /* = jobs */; u += gridDim.x) {
+        const uint32_t job = u / row_blocks;
+        const uint32_t r = (u - job * row_blocks) * BLOCK + threadIdx.x;
+        const uint32_t rr = r < A.rows ? r : A.rows - 1;           // keep the wave uniform; surplus lanes recompute the last row
+        double o0, o1, o2;
+        uint32_t unused = 0;
+        Item I{};
+        I.Y = (double)(A.y0 + (rr / A.blk_rows) * A.blk_stride + rr % A.blk_rows);
+        I.xmin = 0.0; I.xmax = (double)(A.w - 1u); I.ymin = I.Y; I.ymax = I.Y;
+        I.yout = A.yout + (size_t)rr * A.n_yvals;
+        if (A.xtape) {
+            I.yrow = A.consts;                                         // no y values in a ROW section: any readable address
+            park_specials(A, slots, I);
+            run_xtape<false, MODE_ROW>(A, A.xtape + A.job_off[job], A.job_len[job], nullptr, nullptr, slots, I, o0, o1, o2, unused);
+        } else
+            run_tape<false, MODE_ROW>(A, A.tape + A.job_off[job], A.job_len[job], nullptr, nullptr, slots, spill_base, spill_stride, I, o0, o1, o2, unused);
+    }
 }
 
 // GUARDS kernel: one work-item per rectangle of guard_rows rows x 256 pixels, blockIdx.y = job (8 guards = one byte
@@ -397,7 +427,12 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_guards(const KArgs A)
         // a group never straddles two row blocks (the host picks guard_rows | blk_rows): its image rows are consecutive
         I.Y = (double)(A.y0 + (r / A.blk_rows) * A.blk_stride + r % A.blk_rows);
         I.xmin = (double)xlo; I.xmax = (double)xhi; I.ymin = I.Y; I.ymax = I.Y + (double)(r_last - r);
-        run_tape<false, MODE_GUARDS>(A, A.tape + A.job_off[job], A.job_len[job], nullptr, nullptr, slots, spill_base, spill_stride, I, o0, o1, o2, bits);
+        if (A.xtape) {
+            I.yrow = A.consts;
+            park_specials(A, slots, I);
+            run_xtape<false, MODE_GUARDS>(A, A.xtape + A.job_off[job], A.job_len[job], nullptr, nullptr, slots, I, o0, o1, o2, bits);
+        } else
+            run_tape<false, MODE_GUARDS>(A, A.tape + A.job_off[job], A.job_len[job], nullptr, nullptr, slots, spill_base, spill_stride, I, o0, o1, o2, bits);
         if (it < n_items) ((unsigned char *)A.gbits)[(size_t)item * (A.guard_w32 * 4u) + job] = (unsigned char)bits;
     }
 }
@@ -411,19 +446,22 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_guards(const KArgs A)
 
 // PIXEL section -> xtape (see run_xtape).  guard_first: y values from this index on are read as guard bits by SKIP ops
 // (0xFFFFFFFF: none are).
-std::vector<uint64_t> predecode_pixels(const maray_program &P, uint32_t x_slot, uint32_t guard_first)
+std::vector<uint64_t> predecode(const maray_program &P, const uint64_t *ops, uint32_t n_ops, uint32_t x_slot, uint32_t guard_first)
 {
-    std::vector<uint64_t> out(P.n_pix_ops, 0);
+    std::vector<uint64_t> out(n_ops, 0);
     auto operand = [&](uint32_t ref, uint32_t &k, uint32_t &idx) {
         const uint32_t kind = MARAY_REF_KIND(ref), i = MARAY_REF_INDEX(ref);
         if (kind == MARAY_K_SLOT) { k = XS; idx = i; }
         else if (kind == MARAY_K_CONST) { k = XU; idx = i; }
         else if (kind == MARAY_K_YVAL) { k = XU; idx = P.n_consts + i; }
         else if (i == MARAY_SPEC_ACC) { k = XA; idx = 0; }
-        else { k = XS; idx = x_slot + (i == MARAY_SPEC_X ? 0u : 1u); }      // the validator admits only X, Y, ACC here
+        else {
+            static const uint32_t park[] = {0, 1, 0, 4, 3, 6, 5};          // X, Y, -, XMAX, XMIN, YMAX, YMIN -> reserved slot
+            k = XS; idx = x_slot + park[i];
+        }
     };
-    for (uint32_t j = 0; j < P.n_pix_ops; j++) {
-        const uint64_t ins = P.pix_ops[j];
+    for (uint32_t j = 0; j < n_ops; j++) {
+        const uint64_t ins = ops[j];
         const uint32_t op = MARAY_INS_OP(ins), aux = MARAY_INS_AUX(ins);
         uint32_t dst = MARAY_INS_DST(ins);
         if (dst == MARAY_DST_NONE) dst = x_slot + 2;
@@ -477,7 +515,7 @@ struct TapeBackend final : Backend {
     // cut into the cone of the operand y values (run per row) and the cones of the guards, 32 to a job (run per
     // rectangle of 8 rows x 256 pixels by maray_tape_guards); the pixel kernel then reads guard bits.
     bool tile_guards = false;
-    uint32_t n_ynum = 0, n_row_ops_rows = 0, n_guard_jobs = 0, n_guard_w32 = 0;
+    uint32_t n_ynum = 0, n_guard_jobs = 0, n_guard_w32 = 0;
     uint32_t rows_slots = 0, guard_slots = 0;          // value slots of the cut tapes (renumbered by liveness)
     uint32_t guard_lds_slots = 0, guard_lds_bytes = 0;
     uint64_t *d_guard_ops = nullptr;
@@ -486,6 +524,11 @@ struct TapeBackend final : Backend {
     // PIXEL section pre-decoded for run_xtape: one variant reads guards as bits, one as y values (the drain)
     uint64_t *d_xtape_bits = nullptr, *d_xtape_rows = nullptr;
     uint32_t x_slot = 0;
+    // ... and the ROW tape and the guard jobs (specials parked in 7 reserved slots after the tape's own)
+    uint64_t *d_xrows = nullptr, *d_xguards = nullptr;
+    uint32_t *d_row_job_off = nullptr, *d_row_job_len = nullptr;
+    uint32_t n_row_jobs = 0;
+    uint32_t xrows_slot = 0, xguards_slot = 0;
     unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;
     double *d_rgb64 = nullptr; size_t rgb64_cap = 0;
     hipStream_t own_stream = nullptr;
@@ -500,7 +543,8 @@ struct TapeBackend final : Backend {
         for (auto p : d_tex_rgb) (void)hipFree(p);
         (void)hipFree(d_yvals); (void)hipFree(d_spill); (void)hipFree(d_rgb8); (void)hipFree(d_rgb64);
         (void)hipFree(d_guard_ops); (void)hipFree(d_job_off); (void)hipFree(d_job_len); (void)hipFree(d_gbits);
-        (void)hipFree(d_xtape_bits); (void)hipFree(d_xtape_rows);
+        (void)hipFree(d_xtape_bits); (void)hipFree(d_xtape_rows); (void)hipFree(d_xrows); (void)hipFree(d_xguards);
+        (void)hipFree(d_row_job_off); (void)hipFree(d_row_job_len);
         if (own_stream) (void)hipStreamDestroy(own_stream);
     }
 
@@ -518,17 +562,35 @@ struct TapeBackend final : Backend {
             if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
         };
         n_ynum = numeric_yvals(prog);
-        n_row_ops_rows = prog.n_row_ops;
         const uint32_t n_guards = prog.n_yvals - n_ynum;
         tile_guards = n_guards > 0 && prog.n_row_ops > 0 && !any_guard_reads_y(prog) && !getenv("MARAY_TAPE_ROW_GUARDS");
+        std::vector<uint64_t> rows_host, guards_host;
+        const bool keep_order = getenv("MARAY_TAPE_KEEP_ORDER") != nullptr;
+        const RowTapeDeps deps = row_tape_deps(prog);
+        {
+            // ROW kernel jobs: 8 y values each -- the ones PIXEL ops read as operands, and (when guards are evaluated
+            // per row, as y values) the guards as well
+            const uint32_t n_row_outs = tile_guards ? n_ynum : prog.n_yvals;
+            n_row_jobs = prog.n_row_ops ? (n_row_outs + 7) / 8 : 0;
+            std::vector<uint32_t> off, len;
+            for (uint32_t j = 0; j < n_row_jobs; j++) {
+                std::vector<uint32_t> outs;
+                for (uint32_t o : deps.outs) {
+                    const uint32_t aux = MARAY_INS_AUX(prog.row_ops[o]);
+                    if (aux >= 8 * j && aux < 8 * (j + 1) && aux < n_row_outs) outs.push_back(o);
+                }
+                std::vector<uint64_t> t = compact_tape(row_tape_cone(prog, deps, outs, nullptr));
+                rows_slots = std::max(rows_slots, keep_order ? renumber_slots(t) : reschedule_tape(t));
+                if (t.empty()) continue;
+                off.push_back((uint32_t)rows_host.size()); len.push_back((uint32_t)t.size());
+                rows_host.insert(rows_host.end(), t.begin(), t.end());
+            }
+            n_row_jobs = (uint32_t)off.size();
+            up(rows_host.data(), rows_host.size() * 8, (void **)&d_row_ops);
+            up(off.data(), off.size() * 4, (void **)&d_row_job_off);
+            up(len.data(), len.size() * 4, (void **)&d_row_job_len);
+        }
         if (tile_guards) {
-            const RowTapeDeps deps = row_tape_deps(prog);
-            std::vector<uint32_t> num_outs;
-            for (uint32_t o : deps.outs) if (MARAY_INS_AUX(prog.row_ops[o]) < n_ynum) num_outs.push_back(o);
-            std::vector<uint64_t> rows_tape = compact_tape(row_tape_cone(prog, deps, num_outs, nullptr));
-            rows_slots = renumber_slots(rows_tape);
-            n_row_ops_rows = (uint32_t)rows_tape.size();
-            up(rows_tape.data(), rows_tape.size() * 8, (void **)&d_row_ops);
             n_guard_jobs = (n_guards + 7) / 8;
             n_guard_w32 = (n_guards + 31) / 32;
             std::vector<uint64_t> all;
@@ -540,15 +602,15 @@ struct TapeBackend final : Backend {
                     if (aux >= n_ynum + 8 * j && aux < n_ynum + 8 * (j + 1)) outs.push_back(o);
                 }
                 std::vector<uint64_t> t = compact_tape(row_tape_cone(prog, deps, outs, nullptr));
-                guard_slots = std::max(guard_slots, renumber_slots(t));
+                guard_slots = std::max(guard_slots, keep_order ? renumber_slots(t) : reschedule_tape(t));
                 off[j] = (uint32_t)all.size(); len[j] = (uint32_t)t.size();
                 all.insert(all.end(), t.begin(), t.end());
             }
+            guards_host = all;
             up(all.data(), all.size() * 8, (void **)&d_guard_ops);
             up(off.data(), off.size() * 4, (void **)&d_job_off);
             up(len.data(), len.size() * 4, (void **)&d_job_len);
-        } else
-            up(prog.row_ops, (size_t)prog.n_row_ops * 8, (void **)&d_row_ops);
+        }
         up(prog.pix_ops, (size_t)prog.n_pix_ops * 8, (void **)&d_pix_ops);
         up(prog.consts, (size_t)prog.n_consts * 8, (void **)&d_consts);
         std::vector<MarayTex> descs(n_tex ? n_tex : 1);
@@ -571,22 +633,39 @@ struct TapeBackend final : Backend {
         n_lds_slots = (uint32_t)std::min<size_t>(prog.n_pix_slots, (lds_cap - base) / slot_bytes);
         lds_bytes = (uint32_t)(base + (size_t)n_lds_slots * slot_bytes);
         blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, lds_cap / std::max<uint32_t>(lds_bytes, 1)));
-        if (!tile_guards) rows_slots = prog.n_row_slots;
         row_lds_slots = (uint32_t)std::min<size_t>(rows_slots, 65536 / slot_bytes);
         row_lds_bytes = (uint32_t)(row_lds_slots * slot_bytes);
         guard_lds_slots = (uint32_t)std::min<size_t>(guard_slots, 40);       // 80 KB: two blocks per CU; the rest spills
         guard_lds_bytes = (uint32_t)(guard_lds_slots * slot_bytes);
         if (tile_guards) HIP_TRY(hipFuncSetAttribute((const void *)maray_tape_guards, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+        HIP_TRY(hipFuncSetAttribute((const void *)maray_tape_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+        if (!getenv("MARAY_TAPE_GENERIC")) {
+            // ROW tape and guard jobs through the pre-decoded loop when all their slots (+ 7 parked specials) fit LDS
+            if (!rows_host.empty() && ((size_t)rows_slots + 7) * slot_bytes <= lds_cap) {
+                xrows_slot = rows_slots;
+                row_lds_slots = rows_slots + 7;
+                row_lds_bytes = (uint32_t)(row_lds_slots * slot_bytes);
+                const std::vector<uint64_t> x = predecode(prog, rows_host.data(), (uint32_t)rows_host.size(), xrows_slot, 0xFFFFFFFFu);
+                up(x.data(), x.size() * 8, (void **)&d_xrows);
+            }
+            if (tile_guards && ((size_t)guard_slots + 7) * slot_bytes <= lds_cap) {
+                xguards_slot = guard_slots;
+                guard_lds_slots = guard_slots + 7;
+                guard_lds_bytes = (uint32_t)(guard_lds_slots * slot_bytes);
+                const std::vector<uint64_t> x = predecode(prog, guards_host.data(), (uint32_t)guards_host.size(), xguards_slot, 0xFFFFFFFFu);
+                up(x.data(), x.size() * 8, (void **)&d_xguards);
+            }
+        }
         // the pre-decoded loop needs every slot in LDS plus three (X, Y, trash)
         if (base + ((size_t)prog.n_pix_slots + 3) * slot_bytes <= lds_cap && prog.n_pix_slots + 3 < MARAY_DST_NONE && !getenv("MARAY_TAPE_GENERIC")) {
             x_slot = prog.n_pix_slots;
             n_lds_slots = prog.n_pix_slots + 3;
             lds_bytes = (uint32_t)(base + (size_t)n_lds_slots * slot_bytes);
             blocks_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, lds_cap / std::max<uint32_t>(lds_bytes, 1)));
-            const std::vector<uint64_t> xr = predecode_pixels(prog, x_slot, 0xFFFFFFFFu);
+            const std::vector<uint64_t> xr = predecode(prog, prog.pix_ops, prog.n_pix_ops, x_slot, 0xFFFFFFFFu);
             up(xr.data(), xr.size() * 8, (void **)&d_xtape_rows);
             if (tile_guards) {
-                const std::vector<uint64_t> xb = predecode_pixels(prog, x_slot, n_ynum);
+                const std::vector<uint64_t> xb = predecode(prog, prog.pix_ops, prog.n_pix_ops, x_slot, n_ynum);
                 up(xb.data(), xb.size() * 8, (void **)&d_xtape_bits);
             }
         }
@@ -626,19 +705,24 @@ struct TapeBackend final : Backend {
             ensure(d_gbits, gbits_cap, (size_t)n_groups * tiles_per_row * n_guard_w32);
             if (gbits_cap != had) HIP_TRY(hipMemsetAsync(d_gbits, 0, gbits_cap * 4, st));     // bytes past the last job are never written
         }
-        if (rows_pass && P.n_row_ops) {
+        if (rows_pass && (n_row_jobs || bits)) {
             KArgs R{};
             R.tape = d_row_ops; R.consts = d_consts; R.yout = d_yvals; R.tex = d_tex;
-            R.n_ops = n_row_ops_rows; R.n_consts = P.n_consts; R.n_yvals = P.n_yvals;
+            R.n_ops = 0; R.n_tiles = n_row_jobs; R.job_off = d_row_job_off; R.job_len = d_row_job_len;
+            R.n_consts = P.n_consts; R.n_yvals = P.n_yvals;
             R.n_slots = rows_slots; R.n_lds_slots = row_lds_slots;
+            R.xtape = d_xrows; R.x_slot = xrows_slot;
             R.w = w; R.y0 = y0; R.rows = rows; R.blk_rows = rb.block_rows; R.blk_stride = rb.block_stride;
-            const uint32_t grid = (rows + BLOCK - 1) / BLOCK;
-            if (rows_slots > row_lds_slots) {
+            const uint64_t row_units = (uint64_t)((rows + BLOCK - 1) / BLOCK) * n_row_jobs;
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(row_units, 1), (uint64_t)prop.multiProcessorCount * 4);
+            if (n_row_jobs && rows_slots > row_lds_slots) {
                 ensure(d_spill, spill_cap, std::max(spill_cap, (size_t)(rows_slots - row_lds_slots) * grid * BLOCK));
                 R.spill = d_spill;
             }
-            hipLaunchKernelGGL(maray_tape_rows, dim3(grid), dim3(BLOCK), row_lds_bytes, st, R);
-            HIP_TRY(hipGetLastError());
+            if (n_row_jobs) {
+                hipLaunchKernelGGL(maray_tape_rows, dim3(grid), dim3(BLOCK), row_lds_bytes, st, R);
+                HIP_TRY(hipGetLastError());
+            }
             if (bits) {
                 KArgs G = R;
                 G.tape = d_guard_ops; G.yout = nullptr;
@@ -650,6 +734,7 @@ struct TapeBackend final : Backend {
                 const uint32_t ggrid = (uint32_t)std::min<uint64_t>(units, (uint64_t)prop.multiProcessorCount * 2);
                 G.spill = nullptr;
                 G.n_slots = guard_slots; G.n_lds_slots = guard_lds_slots;
+                G.xtape = d_xguards; G.x_slot = xguards_slot;
                 G.n_tiles = n_guard_jobs;                                                       // the GUARDS kernel reads its job count here
                 if (guard_slots > guard_lds_slots) {
                     ensure(d_spill, spill_cap, std::max(spill_cap, (size_t)(guard_slots - guard_lds_slots) * ggrid * BLOCK));

@@ -178,6 +178,148 @@ uint32_t renumber_slots(std::vector<uint64_t> &tape)
     return used;
 }
 
+// Re-orders a (compacted) cone of the ROW tape and allocates its value slots afresh.  Returns the slots used.
+//
+// A cone keeps the order the whole section was scheduled in: values that other cones wanted first sit at the front and
+// stay live until this cone gets round to them -- 150 slots live at once for a guard whose expression tree needs a
+// dozen.  The interpreter keeps slots in LDS (2 KB each per block), so the live set IS its occupancy.  Here the cone is
+// scheduled on its own: units (an op, or a SKIP region with everything up to the op that ends it, kept verbatim) in
+// depth-first order from each OUT, the operand that needs more slots first (Sethi-Ullman), results handed over through
+// ACC when producer and consumer end up adjacent, slots by liveness over the new order.  (Kept only if it needs fewer
+// slots than the original order does.)
+uint32_t reschedule_tape(std::vector<uint64_t> &tape)
+{
+    const uint32_t n = (uint32_t)tape.size();
+    if (!n) return 0;
+    auto is_skip = [&](uint32_t j) { const uint32_t op = MARAY_INS_OP(tape[j]); return op == MARAY_OP_SKIPZ || op == MARAY_OP_SKIPNZ; };
+    auto is_out = [&](uint32_t j) { return MARAY_INS_OP(tape[j]) == MARAY_OP_OUT; };
+    // units
+    std::vector<uint32_t> unit_of(n), ubegin, uend;
+    for (uint32_t j = 0; j < n;) {
+        uint32_t e = j;
+        for (uint32_t k = j; k <= e && k < n; k++)
+            if (is_skip(k)) e = std::max(e, std::min(n - 1, k + MARAY_INS_AUX(tape[k])));
+        for (uint32_t k = j; k <= e; k++) unit_of[k] = (uint32_t)ubegin.size();
+        ubegin.push_back(j); uend.push_back(e);
+        j = e + 1;
+    }
+    const uint32_t nu = (uint32_t)ubegin.size();
+    // values: a value is named by the op that ends its definition (a SKIP op with a dst defines its region's value)
+    std::vector<int32_t> ua(n, -1), ub(n, -1);
+    {
+        std::vector<int32_t> cur(MARAY_DST_NONE + 1, -1);
+        int32_t acc = -1;
+        auto value = [&](uint32_t ref) -> int32_t {
+            if (MARAY_REF_KIND(ref) == MARAY_K_SLOT) return cur[MARAY_REF_INDEX(ref)];
+            if (MARAY_REF_KIND(ref) == MARAY_K_SPEC && MARAY_REF_INDEX(ref) == MARAY_SPEC_ACC) return acc;
+            return -1;
+        };
+        for (uint32_t j = 0; j < n; j++) {
+            const uint64_t ins = tape[j];
+            const uint32_t op = MARAY_INS_OP(ins), dst = MARAY_INS_DST(ins);
+            if (op == MARAY_OP_NOP) continue;
+            if (op != MARAY_OP_TEXDIM) ua[j] = value(MARAY_INS_A(ins));
+            if (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) ub[j] = value(MARAY_INS_B(ins));
+            if (op == MARAY_OP_OUT) continue;
+            if (is_skip(j)) { if (dst != MARAY_DST_NONE) cur[dst] = (int32_t)std::min(n - 1, j + MARAY_INS_AUX(ins)); continue; }
+            acc = (int32_t)j;
+            if (dst != MARAY_DST_NONE) cur[dst] = (int32_t)j;
+        }
+    }
+    // unit DAG; the original order is a topological order of it
+    std::vector<std::vector<uint32_t>> kids(nu);
+    for (uint32_t j = 0; j < n; j++)
+        for (int32_t v : {ua[j], ub[j]})
+            if (v >= 0 && unit_of[v] != unit_of[j]) kids[unit_of[j]].push_back(unit_of[v]);
+    std::vector<uint32_t> need(nu, 1);
+    for (uint32_t u = 0; u < nu; u++) {
+        auto &k = kids[u];
+        std::sort(k.begin(), k.end());
+        k.erase(std::unique(k.begin(), k.end()), k.end());
+        std::stable_sort(k.begin(), k.end(), [&](uint32_t x, uint32_t y) { return need[x] > need[y]; });
+        for (uint32_t i = 0; i < k.size(); i++) need[u] = std::max(need[u], need[k[i]] + i);
+    }
+    std::vector<uint32_t> seq;
+    seq.reserve(n);
+    {
+        std::vector<uint8_t> done(nu, 0);
+        std::vector<std::pair<uint32_t, uint32_t>> stack;
+        for (uint32_t r = 0; r < nu; r++) {
+            if (!is_out(ubegin[r]) || done[r]) continue;
+            stack.push_back({r, 0});
+            done[r] = 1;
+            while (!stack.empty()) {
+                auto &top = stack.back();
+                if (top.second < kids[top.first].size()) {
+                    const uint32_t c = kids[top.first][top.second++];
+                    if (!done[c]) { done[c] = 1; stack.push_back({c, 0}); }
+                    continue;
+                }
+                for (uint32_t k = ubegin[top.first]; k <= uend[top.first]; k++) seq.push_back(k);
+                stack.pop_back();
+            }
+        }
+    }
+    const uint32_t m = (uint32_t)seq.size();
+    std::vector<int32_t> newpos(n, -1);
+    for (uint32_t p = 0; p < m; p++) newpos[seq[p]] = (int32_t)p;
+    // may the op at position p read value v through ACC?  SKIP ops (not taken, or p is not reached) and OUT ops leave ACC alone
+    auto acc_ok = [&](uint32_t p, int32_t v) {
+        int32_t q = (int32_t)p - 1;
+        while (q >= 0 && (is_skip(seq[q]) || is_out(seq[q]))) q--;
+        return q >= 0 && (int32_t)seq[q] == v;
+    };
+    std::vector<uint8_t> needs_slot(n, 0);
+    std::vector<int32_t> last_use(n, -1), first_def(n, -1);
+    for (uint32_t p = 0; p < m; p++) {
+        const uint32_t j = seq[p];
+        for (int32_t v : {ua[j], ub[j]}) {
+            if (v < 0) continue;
+            if (!acc_ok(p, v)) { needs_slot[v] = 1; last_use[v] = (int32_t)p; }
+        }
+        if (is_out(j)) continue;
+        const int32_t v = is_skip(j) ? (int32_t)std::min(n - 1, j + MARAY_INS_AUX(tape[j])) : (int32_t)j;
+        if (first_def[v] < 0) first_def[v] = (int32_t)p;
+        if (is_skip(j)) continue;
+        // a region's value lives to the op that ends it at least
+        if (first_def[v] != (int32_t)p) last_use[v] = std::max(last_use[v], (int32_t)p);
+    }
+    std::vector<std::vector<int32_t>> dies(m);
+    for (uint32_t v = 0; v < n; v++) if (needs_slot[v] && last_use[v] >= 0) dies[last_use[v]].push_back((int32_t)v);
+    std::vector<int32_t> slot_of(n, -1);
+    std::vector<uint32_t> free_list;
+    uint32_t used = 0;
+    std::vector<uint64_t> out(m);
+    for (uint32_t p = 0; p < m; p++) {
+        const uint32_t j = seq[p];
+        const uint64_t ins = tape[j];
+        const uint32_t op = MARAY_INS_OP(ins);
+        uint32_t a = MARAY_INS_A(ins), b = MARAY_INS_B(ins), dst = MARAY_DST_NONE;
+        const uint32_t acc_ref = MARAY_REF(MARAY_K_SPEC, MARAY_SPEC_ACC);
+        if (ua[j] >= 0) a = acc_ok(p, ua[j]) ? acc_ref : MARAY_REF(MARAY_K_SLOT, (uint32_t)slot_of[ua[j]]);
+        if (ub[j] >= 0) b = acc_ok(p, ub[j]) ? acc_ref : MARAY_REF(MARAY_K_SLOT, (uint32_t)slot_of[ub[j]]);
+        const int32_t v = is_out(j) ? -1 : (is_skip(j) ? (int32_t)std::min(n - 1, j + MARAY_INS_AUX(ins)) : (int32_t)j);
+        // operands are read before the result is written: a value that dies here may hand its slot to this op's result
+        for (int32_t d : dies[p]) if (d != v) free_list.push_back((uint32_t)slot_of[d]);
+        if (v >= 0 && needs_slot[v]) {
+            if (slot_of[v] < 0) {
+                if (free_list.empty()) free_list.push_back(used++);
+                slot_of[v] = (int32_t)free_list.back();
+                free_list.pop_back();
+            }
+            dst = (uint32_t)slot_of[v];
+        }
+        for (int32_t d : dies[p]) if (d == v) free_list.push_back((uint32_t)slot_of[d]);
+        out[p] = MARAY_INS(op, MARAY_INS_AUX(ins), dst, a, b);
+    }
+    // a cone with many outputs can do better in the order the section was scheduled in: never return the worse of the two
+    std::vector<uint64_t> kept = tape;
+    const uint32_t used_kept = renumber_slots(kept);
+    if (used_kept <= used) { tape.swap(kept); return used_kept; }
+    tape.swap(out);
+    return used;
+}
+
 bool any_guard_reads_y(const maray_program &P)
 {
     const RowTapeDeps d = row_tape_deps(P);
