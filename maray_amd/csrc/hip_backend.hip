@@ -53,6 +53,8 @@ struct KArgs {
     // guard guard_first + g.  PIXEL reads them instead of y values; the GUARDS kernel (job j = 8 guards = one byte,
     // tape[job_off[j] .. + job_len[j])) writes them.
     uint32_t *gbits;
+    uint32_t *queue;           // GUARDS: next (job, block of items) unit to hand out (zeroed before the launch)
+    const uint32_t *job_id;    // GUARDS: jobs are listed longest first; job_id[k] = which byte of the guard bits job k writes
     const uint64_t *xtape;     // PIXEL: the section pre-decoded for run_xtape, or null (generic loop)
     uint32_t x_slot;           // run_xtape: slots x_slot, x_slot + 1, x_slot + 2 hold X, Y and the results nothing reads
     const uint32_t *job_off, *job_len;
@@ -413,8 +415,16 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_guards(const KArgs A)
     const uint32_t n_groups = (A.rows + A.guard_rows - 1) / A.guard_rows;
     const uint32_t n_items = n_groups * A.tiles_per_row;
     const uint32_t item_blocks = (n_items + BLOCK - 1) / BLOCK;
-    // blocks stride over (job, block of items) pairs: the grid, and with it the spill area, stays bounded for any image
-    for (uint32_t u = blockIdx.x; u < item_blocks * A.n_tiles /* = jobs */; u += gridDim.x) {
+    // resident blocks draw (job, block of items) units from a queue, longest jobs first: the grid, and with it the spill
+    // area, stays bounded for any image, and a block that drew a short job comes back for more while a long one runs.
+    // Every block ends with a draw past the last unit.
+    __shared__ uint32_t drawn;
+    for (;;) {
+        __syncthreads();                                               // the previous unit's reads of `drawn` are done
+        if (threadIdx.x == 0) drawn = atomicAdd(A.queue, 1u);
+        __syncthreads();
+        const uint32_t u = drawn;
+        if (u >= item_blocks * A.n_tiles /* = jobs */) break;
         const uint32_t job = u / item_blocks;
         const uint32_t it = (u - job * item_blocks) * BLOCK + threadIdx.x;
         const uint32_t item = it < n_items ? it : n_items - 1;         // keep the wave uniform
@@ -433,7 +443,7 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_guards(const KArgs A)
             run_xtape<false, MODE_GUARDS>(A, A.xtape + A.job_off[job], A.job_len[job], nullptr, nullptr, slots, I, o0, o1, o2, bits);
         } else
             run_tape<false, MODE_GUARDS>(A, A.tape + A.job_off[job], A.job_len[job], nullptr, nullptr, slots, spill_base, spill_stride, I, o0, o1, o2, bits);
-        if (it < n_items) ((unsigned char *)A.gbits)[(size_t)item * (A.guard_w32 * 4u) + job] = (unsigned char)bits;
+        if (it < n_items) ((unsigned char *)A.gbits)[(size_t)item * (A.guard_w32 * 4u) + A.job_id[job]] = (unsigned char)bits;
     }
 }
 
@@ -526,7 +536,7 @@ struct TapeBackend final : Backend {
     uint32_t x_slot = 0;
     // ... and the ROW tape and the guard jobs (specials parked in 7 reserved slots after the tape's own)
     uint64_t *d_xrows = nullptr, *d_xguards = nullptr;
-    uint32_t *d_row_job_off = nullptr, *d_row_job_len = nullptr;
+    uint32_t *d_row_job_off = nullptr, *d_row_job_len = nullptr, *d_job_id = nullptr, *d_queue = nullptr;
     uint32_t n_row_jobs = 0;
     uint32_t xrows_slot = 0, xguards_slot = 0;
     unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;
@@ -544,7 +554,7 @@ struct TapeBackend final : Backend {
         (void)hipFree(d_yvals); (void)hipFree(d_spill); (void)hipFree(d_rgb8); (void)hipFree(d_rgb64);
         (void)hipFree(d_guard_ops); (void)hipFree(d_job_off); (void)hipFree(d_job_len); (void)hipFree(d_gbits);
         (void)hipFree(d_xtape_bits); (void)hipFree(d_xtape_rows); (void)hipFree(d_xrows); (void)hipFree(d_xguards);
-        (void)hipFree(d_row_job_off); (void)hipFree(d_row_job_len);
+        (void)hipFree(d_row_job_off); (void)hipFree(d_row_job_len); (void)hipFree(d_job_id); (void)hipFree(d_queue);
         if (own_stream) (void)hipStreamDestroy(own_stream);
     }
 
@@ -593,8 +603,7 @@ struct TapeBackend final : Backend {
         if (tile_guards) {
             n_guard_jobs = (n_guards + 7) / 8;
             n_guard_w32 = (n_guards + 31) / 32;
-            std::vector<uint64_t> all;
-            std::vector<uint32_t> off(n_guard_jobs), len(n_guard_jobs);
+            std::vector<std::vector<uint64_t>> cones(n_guard_jobs);
             for (uint32_t j = 0; j < n_guard_jobs; j++) {
                 std::vector<uint32_t> outs;
                 for (uint32_t o : deps.outs) {
@@ -603,9 +612,18 @@ struct TapeBackend final : Backend {
                 }
                 std::vector<uint64_t> t = compact_tape(row_tape_cone(prog, deps, outs, nullptr));
                 guard_slots = std::max(guard_slots, keep_order ? renumber_slots(t) : reschedule_tape(t));
-                off[j] = (uint32_t)all.size(); len[j] = (uint32_t)t.size();
-                all.insert(all.end(), t.begin(), t.end());
+                cones[j].swap(t);
             }
+            std::vector<uint32_t> ids(n_guard_jobs), off(n_guard_jobs), len(n_guard_jobs);
+            for (uint32_t j = 0; j < n_guard_jobs; j++) ids[j] = j;
+            std::stable_sort(ids.begin(), ids.end(), [&](uint32_t x, uint32_t y) { return cones[x].size() > cones[y].size(); });
+            std::vector<uint64_t> all;
+            for (uint32_t k = 0; k < n_guard_jobs; k++) {
+                off[k] = (uint32_t)all.size(); len[k] = (uint32_t)cones[ids[k]].size();
+                all.insert(all.end(), cones[ids[k]].begin(), cones[ids[k]].end());
+            }
+            up(ids.data(), ids.size() * 4, (void **)&d_job_id);
+            HIP_TRY(hipMalloc((void **)&d_queue, 4));
             guards_host = all;
             up(all.data(), all.size() * 8, (void **)&d_guard_ops);
             up(off.data(), off.size() * 4, (void **)&d_job_off);
@@ -637,7 +655,7 @@ struct TapeBackend final : Backend {
         row_lds_bytes = (uint32_t)(row_lds_slots * slot_bytes);
         guard_lds_slots = (uint32_t)std::min<size_t>(guard_slots, 40);       // 80 KB: two blocks per CU; the rest spills
         guard_lds_bytes = (uint32_t)(guard_lds_slots * slot_bytes);
-        if (tile_guards) HIP_TRY(hipFuncSetAttribute((const void *)maray_tape_guards, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+        if (tile_guards) HIP_TRY(hipFuncSetAttribute((const void *)maray_tape_guards, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap - 64));
         HIP_TRY(hipFuncSetAttribute((const void *)maray_tape_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
         if (!getenv("MARAY_TAPE_GENERIC")) {
             // ROW tape and guard jobs through the pre-decoded loop when all their slots (+ 7 parked specials) fit LDS
@@ -648,7 +666,7 @@ struct TapeBackend final : Backend {
                 const std::vector<uint64_t> x = predecode(prog, rows_host.data(), (uint32_t)rows_host.size(), xrows_slot, 0xFFFFFFFFu);
                 up(x.data(), x.size() * 8, (void **)&d_xrows);
             }
-            if (tile_guards && ((size_t)guard_slots + 7) * slot_bytes <= lds_cap) {
+            if (tile_guards && ((size_t)guard_slots + 7) * slot_bytes + 64 <= lds_cap) {      // + the kernel's static LDS
                 xguards_slot = guard_slots;
                 guard_lds_slots = guard_slots + 7;
                 guard_lds_bytes = (uint32_t)(guard_lds_slots * slot_bytes);
@@ -731,7 +749,10 @@ struct TapeBackend final : Backend {
                 const uint64_t items = (uint64_t)n_groups * tiles_per_row;
                 if (items > 0x7FFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
                 const uint64_t units = ((items + BLOCK - 1) / BLOCK) * n_guard_jobs;        // (job, block of items) pairs
-                const uint32_t ggrid = (uint32_t)std::min<uint64_t>(units, (uint64_t)prop.multiProcessorCount * 2);
+                const uint32_t resident = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, 163840 / std::max<uint32_t>(guard_lds_bytes, 1)));
+                const uint32_t ggrid = (uint32_t)std::min<uint64_t>(units, (uint64_t)prop.multiProcessorCount * resident);
+                G.queue = d_queue; G.job_id = d_job_id;
+                HIP_TRY(hipMemsetAsync(d_queue, 0, 4, st));
                 G.spill = nullptr;
                 G.n_slots = guard_slots; G.n_lds_slots = guard_lds_slots;
                 G.xtape = d_xguards; G.x_slot = xguards_slot;
