@@ -1,4 +1,4 @@
-// lower_asan.cpp — host-only sanitizer harness for the product's reader, fix_color, simplify and lowering
+// lower_asan.cpp — host-only sanitizer harness for the product's reader, fix_color, simplify, lowering and ROW-tape cuts
 // (test infrastructure).  Built with -fsanitize=address,undefined together with scene.cpp and lower.cpp;
 // reads .maray files given on the command line, lowers each with several option sets and validates the
 // resulting programs structurally.
@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 
+#include "backend.hpp"
 #include "expr.hpp"
 #include "lower.hpp"
 
@@ -74,6 +75,19 @@ static int real_main(int argc, char **argv)
                 try { lower_scene(s, o, t); }
                 catch (const Error &e) { if (e.code != MARAY_E_ALIASED && e.code != MARAY_E_CYCLE) { fprintf(stderr, "%s: %s\n", argv[i], e.msg.c_str()); return 1; } rejected++; continue; }
                 validate_program(t.program());
+                // the cuts the evaluators make of the ROW section (row_split.cpp): every job of 8 y values, both slot allocators
+                const maray_program P = t.program();
+                if (P.n_row_ops) {
+                    const RowTapeDeps deps = row_tape_deps(P);
+                    for (uint32_t first = 0; first < P.n_yvals; first += 8) {
+                        std::vector<uint32_t> outs;
+                        for (uint32_t o : deps.outs) { const uint32_t k = MARAY_INS_AUX(P.row_ops[o]); if (k >= first && k < first + 8) outs.push_back(o); }
+                        std::vector<uint64_t> a = compact_tape(row_tape_cone(P, deps, outs, nullptr)), b = a;
+                        const uint32_t na = renumber_slots(a), nb = reschedule_tape(b);
+                        if (nb > na || b.size() > a.size()) { fprintf(stderr, "%s: cone %u: %u > %u slots\n", argv[i], first, nb, na); return 1; }
+                    }
+                    (void)any_guard_reads_y(P); (void)numeric_yvals(P);
+                }
                 lowered++;
             }
         }

@@ -324,6 +324,25 @@ def test_specialised_kernel_variants_selected_by_tuning_knobs(chess_bytes, monke
         assert hashlib.sha256(got8.tobytes()).hexdigest() == g['rgb8_sha256'], env
 
 
+def test_interpreter_variants_selected_by_tuning_knobs(chess_bytes, monkeypatch):
+    """The interpreter's other paths: the generic loop (what a program whose slots do not fit LDS gets, spill area
+    included), guards evaluated per row as y values (what a scene whose guards read Y gets), and cones kept in the
+    order the ROW section was scheduled in (more live slots: LDS + spill)."""
+    g = json.load(open(os.path.join(GOLDEN, 'chess_1024.json')))
+    tape = M.Scene(chess_bytes).lower()
+    for env in ({'MARAY_TAPE_GENERIC': '1'}, {'MARAY_TAPE_ROW_GUARDS': '1'}, {'MARAY_TAPE_KEEP_ORDER': '1'},
+                {'MARAY_TAPE_GENERIC': '1', 'MARAY_TAPE_KEEP_ORDER': '1'}, {'MARAY_TAPE_ROW_GUARDS': '1', 'MARAY_TAPE_GENERIC': '1'}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for b in (M.BACKEND_TAPE_SMEM, M.BACKEND_TAPE):
+            ctx = M.Context(tape, backend=b)
+            got8, _ = ctx.render_rows(1024, 1024, 0, 1024, want_f64=False)
+            ctx.close()
+            assert hashlib.sha256(got8.tobytes()).hexdigest() == g['rgb8_sha256'], (env, b)
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_guarded_shapes_through_inf_and_nan():
     """The scene of tests/test_lowering.py's soundness test on the device, all three evaluators, ragged width."""
     gpu_vs_oracle(encode((192, 24), scenes.shapes_through_inf_and_nan()), 192, 24, [(0, 24)])

@@ -274,3 +274,26 @@ def test_row_section_cut_by_outputs_keeps_every_value(chess_bytes):
                 else:
                     assert part[k] is None
     assert worst <= 72          # what an interpreter has to keep in LDS per work-item: tens of slots, not hundreds
+
+
+@pytest.mark.parametrize('seed,n,mixed', [(3, 12, True), (4, 40, False), (5, 24, 'colours')])
+def test_rescheduled_cones_of_random_shapes_keep_every_value(seed, n, mixed):
+    """row_split.cpp's reschedule_tape on scenes other than chess: every job of 8 y values (what the interpreter's ROW and
+    GUARDS kernels run) reproduces its outputs on rectangles of 8 rows x 64 pixels, SKIP ops taken or not."""
+    import fuzz_scenes
+    w, h = 256, 96
+    tape = M.Scene(encode((w, h), fuzz_scenes.polygon_soup(seed, n, w, h, mixed=mixed))).lower()
+    consts, row_ops, _ = tape.arrays()
+    info = tape.info
+    assert info['n_row_ops'] > 0 and info['n_yvals'] > 8
+    ys = np.arange(0, h, dtype=np.float64)
+    reads_y = tape_eval.guards_reading_y(tape)[1] > 0
+    span, yspan = (64, 127), ((ys, ys) if reads_y else (ys - ys % 8, ys - ys % 8 + 7))
+    full = tape_eval.run_section(row_ops, consts, info['n_row_slots'], None, ys, None, None, info['n_yvals'], w=w, span=span, yspan=yspan)
+    for first in range(0, info['n_yvals'], 8):
+        ops, n_slots = row_cone(tape, first, 8)
+        for honor in (False, True):
+            part = tape_eval.run_section(ops, consts, max(n_slots, 1), None, ys, None, None, info['n_yvals'], honor, w=w, span=span, yspan=yspan)
+            for k in range(first, min(first + 8, info['n_yvals'])):
+                if full[k] is None: continue
+                assert part[k] is not None and same_f64(part[k], full[k]), (first, k, honor)

@@ -24,7 +24,7 @@ def test_reader_and_lowering_under_asan_ubsan(tmp_path):
     subprocess.check_call(['g++', '-std=c++17', '-O1', '-g', '-fsanitize=address,undefined', '-fno-sanitize-recover=all',
                            '-ffp-contract=off', '-I' + csrc, '-I' + os.path.join(ROOT, 'include'),
                            os.path.join(ROOT, 'tests', 'native', 'lower_asan.cpp'), os.path.join(csrc, 'scene.cpp'),
-                           os.path.join(csrc, 'simplify.cpp'), os.path.join(csrc, 'lower.cpp'), shim, '-o', exe, '-lpthread'])
+                           os.path.join(csrc, 'simplify.cpp'), os.path.join(csrc, 'lower.cpp'), os.path.join(csrc, 'row_split.cpp'), shim, '-o', exe, '-lpthread'])
     files = [os.path.join(GOLDEN, 'chess.maray')]
     for k, data in enumerate([encode((64, 64), scenes.all_ops(64, 64)), encode((64, 64), scenes.textured(64))] +
                              [encode((83, 9), scene(seed, n_tex=2 if seed % 3 == 0 else 0)) for seed in range(40)] +
