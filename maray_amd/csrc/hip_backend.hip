@@ -189,7 +189,7 @@ __device__ __forceinline__ void run_tape(const KArgs &A, const uint64_t *tape_g,
 // whose opcode already says where the operands live, and the loop is one jump table:
 //   operand classes  S: value slot in LDS (the item's X, Y -- and in the ROW sections its span XMIN .. YMAX -- are parked
 //                       in reserved slots: x_slot + 0 X, 1 Y, 2 trash, 3 XMIN, 4 XMAX, 5 YMIN, 6 YMAX)
-//                    A: ACC          U: wave-uniform table, index < n_consts -> constant, else y value
+//                    A: ACC          U: wave-uniform table: constant `index`, or with bit 15 set y value `index & 0x7fff`
 //   dst: a slot, or the reserved trash slot (no "if (dst != none)")
 // Same layout as a tape word (op 7 | aux 13 | dst 12 | a 16 | b 16).  Programs whose slots do not fit LDS keep the
 // generic loop.
@@ -216,12 +216,16 @@ __device__ __forceinline__ void run_xtape(const KArgs &A, const uint64_t *xtape,
     k_f64_ptr consts_k = (k_f64_ptr)A.consts;
     k_f64_ptr yrow_k = (k_f64_ptr)I.yrow;
     const __attribute__((address_space(4))) uint32_t *gk_k = (const __attribute__((address_space(4))) uint32_t *)I.gk;
-    const uint32_t nc = A.n_consts;
 #define FS(i) slots[(i) * BLOCK + tid]
-    auto FU = [&](uint32_t i) -> double {          // both tables are read, the index picks: no branch
-        const double c = TAPE_LDS ? consts_lds[i < nc ? i : 0u] : consts_k[i < nc ? i : 0u];
-        const double y = yrow_k[i < nc ? 0u : i - nc];
-        return i < nc ? c : y;
+    auto FU = [&](uint32_t i) -> double {          // bit 15 of the index: a y value of the row, else a constant
+        const uint32_t k = i & 0x7FFFu;
+        if (TAPE_LDS) {                            // both tables are read, the bit picks: no branch
+            const double c = consts_lds[(i & 0x8000u) ? 0u : k];
+            const double y = yrow_k[(i & 0x8000u) ? k : 0u];
+            return (i & 0x8000u) ? y : c;
+        }
+        k_f64_ptr base = (i & 0x8000u) ? yrow_k : consts_k;          // one scalar select of the base, one scalar load
+        return base[k];
     };
     auto FG = [&](uint32_t k, uint32_t i) -> double { return k == XS ? FS(i) : (k == XA ? acc : FU(i)); };   // heavy ops only
     // the ROW kernels run a few wavefronts per CU (their slots fill the LDS): nothing hides the scalar load of the next
@@ -342,8 +346,11 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_pixels(const KArgs A)
     const uint32_t spill_stride = gridDim.x * BLOCK;
     double *spill_base = A.spill ? A.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
 
+    // the first tile of a block is its own, the rest come from a queue: tiles of the board cost tens of times a tile
+    // of sky, and any fixed deal leaves blocks idle (waves were busy 58 % of the launch with a stride of gridDim.x)
+    __shared__ uint32_t drawn;
     const uint32_t n_work = A.tile_list ? A.tile_list[0] : A.n_tiles;      // wave-uniform
-    for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+    for (uint32_t wi = blockIdx.x; wi < n_work;) {
         const uint32_t tile = A.tile_list ? A.tile_list[1 + wi] : wi;
         const uint32_t r = tile / A.tiles_per_row;                 // row within this launch (uniform)
         const uint32_t x = (tile - r * A.tiles_per_row) * BLOCK + threadIdx.x;
@@ -369,6 +376,10 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_pixels(const KArgs A)
                 A.rgb8[p + 2] = (unsigned char)mr_cast_u8(o2);
             }
         }
+        __syncthreads();                                           // the previous draw has been read by every wave
+        if (threadIdx.x == 0) drawn = gridDim.x + atomicAdd(A.queue, 1u);
+        __syncthreads();
+        wi = drawn;
     }
 }
 
@@ -463,7 +474,7 @@ std::vector<uint64_t> predecode(const maray_program &P, const uint64_t *ops, uin
         const uint32_t kind = MARAY_REF_KIND(ref), i = MARAY_REF_INDEX(ref);
         if (kind == MARAY_K_SLOT) { k = XS; idx = i; }
         else if (kind == MARAY_K_CONST) { k = XU; idx = i; }
-        else if (kind == MARAY_K_YVAL) { k = XU; idx = P.n_consts + i; }
+        else if (kind == MARAY_K_YVAL) { k = XU; idx = 0x8000u | i; }
         else if (i == MARAY_SPEC_ACC) { k = XA; idx = 0; }
         else {
             static const uint32_t park[] = {0, 1, 0, 4, 3, 6, 5};          // X, Y, -, XMAX, XMIN, YMAX, YMIN -> reserved slot
@@ -571,6 +582,7 @@ struct TapeBackend final : Backend {
             HIP_TRY(hipMalloc(dst, bytes ? bytes : 8));
             if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
         };
+        HIP_TRY(hipMalloc((void **)&d_queue, 8));               // work queues: [0] guards kernel, [1] pixel kernel
         n_ynum = numeric_yvals(prog);
         const uint32_t n_guards = prog.n_yvals - n_ynum;
         tile_guards = n_guards > 0 && prog.n_row_ops > 0 && !any_guard_reads_y(prog) && !getenv("MARAY_TAPE_ROW_GUARDS");
@@ -623,7 +635,7 @@ struct TapeBackend final : Backend {
                 all.insert(all.end(), cones[ids[k]].begin(), cones[ids[k]].end());
             }
             up(ids.data(), ids.size() * 4, (void **)&d_job_id);
-            HIP_TRY(hipMalloc((void **)&d_queue, 4));
+
             guards_host = all;
             up(all.data(), all.size() * 8, (void **)&d_guard_ops);
             up(off.data(), off.size() * 4, (void **)&d_job_off);
@@ -641,7 +653,7 @@ struct TapeBackend final : Backend {
         up(descs.data(), descs.size() * sizeof(MarayTex), (void **)&d_tex);
 
         // LDS budget: 160 KiB per workgroup on gfx950
-        const size_t lds_cap = 163840;
+        const size_t lds_cap = 163840 - 64;                      // less the kernels' static LDS (the queue draw)
         size_t base = lds_variant ? ((size_t)prog.n_pix_ops + prog.n_consts) * 8 : 0;
         base = (base + 15) & ~(size_t)15;
         tape_lds = lds_variant;
@@ -655,7 +667,7 @@ struct TapeBackend final : Backend {
         row_lds_bytes = (uint32_t)(row_lds_slots * slot_bytes);
         guard_lds_slots = (uint32_t)std::min<size_t>(guard_slots, 40);       // 80 KB: two blocks per CU; the rest spills
         guard_lds_bytes = (uint32_t)(guard_lds_slots * slot_bytes);
-        if (tile_guards) HIP_TRY(hipFuncSetAttribute((const void *)maray_tape_guards, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap - 64));
+        if (tile_guards) HIP_TRY(hipFuncSetAttribute((const void *)maray_tape_guards, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
         HIP_TRY(hipFuncSetAttribute((const void *)maray_tape_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
         if (!getenv("MARAY_TAPE_GENERIC")) {
             // ROW tape and guard jobs through the pre-decoded loop when all their slots (+ 7 parked specials) fit LDS
@@ -666,7 +678,7 @@ struct TapeBackend final : Backend {
                 const std::vector<uint64_t> x = predecode(prog, rows_host.data(), (uint32_t)rows_host.size(), xrows_slot, 0xFFFFFFFFu);
                 up(x.data(), x.size() * 8, (void **)&d_xrows);
             }
-            if (tile_guards && ((size_t)guard_slots + 7) * slot_bytes + 64 <= lds_cap) {      // + the kernel's static LDS
+            if (tile_guards && ((size_t)guard_slots + 7) * slot_bytes <= lds_cap) {
                 xguards_slot = guard_slots;
                 guard_lds_slots = guard_slots + 7;
                 guard_lds_bytes = (uint32_t)(guard_lds_slots * slot_bytes);
@@ -709,6 +721,7 @@ struct TapeBackend final : Backend {
                 const unsigned *tile_list = nullptr, const double *ext_yvals = nullptr) {
         const uint32_t rows = rb.n_rows, y0 = rb.y0;
         if (!rows || !w) return;
+        HIP_TRY(hipMemsetAsync(d_queue, 0, 8, st));              // both kernels' work queues start at 0
         (void)hipGetLastError();        // the launches below are checked with hipGetLastError(): drop what an earlier, unrelated call left
         if (!ext_yvals) ensure(d_yvals, yvals_cap, (size_t)rows * std::max<uint32_t>(P.n_yvals, 1));
         if (ext_yvals) rows_pass = false;
@@ -752,7 +765,6 @@ struct TapeBackend final : Backend {
                 const uint32_t resident = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, 163840 / std::max<uint32_t>(guard_lds_bytes, 1)));
                 const uint32_t ggrid = (uint32_t)std::min<uint64_t>(units, (uint64_t)prop.multiProcessorCount * resident);
                 G.queue = d_queue; G.job_id = d_job_id;
-                HIP_TRY(hipMemsetAsync(d_queue, 0, 4, st));
                 G.spill = nullptr;
                 G.n_slots = guard_slots; G.n_lds_slots = guard_lds_slots;
                 G.xtape = d_xguards; G.x_slot = xguards_slot;
@@ -775,6 +787,7 @@ struct TapeBackend final : Backend {
         A.tiles_per_row = tiles_per_row;
         if (bits) { A.gbits = d_gbits; A.guard_first = n_ynum; A.guard_w32 = n_guard_w32; A.guard_rows = guard_rows; }
         A.xtape = bits ? d_xtape_bits : d_xtape_rows;
+        A.queue = d_queue + 1;
         A.x_slot = x_slot;
         const uint64_t tiles = (uint64_t)A.tiles_per_row * rows;
         if (tiles > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};

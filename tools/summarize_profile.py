@@ -32,7 +32,7 @@ def main():
     for f in sorted(glob.glob(src + '/pmc_*/*/*_counter_collection.csv')):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if r['Kernel_Name'] != kernel:
+            if kernel not in r['Kernel_Name']:
                 continue
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
             res = {k: r[k] for k in ('VGPR_Count', 'Accum_VGPR_Count', 'SGPR_Count', 'Scratch_Size', 'LDS_Block_Size',
