@@ -206,6 +206,18 @@ enum {
     X_SKIPZ = 85, X_SKIPNZ = 89,                  // + class(guard) (XS, XA, XU = a y value bounded over the row, XG)
 };
 
+// The ops with data-dependent branches inside (range reduction, table lookups, bounds checks) are CALLED from the
+// pre-decoded loop: with them inlined, the loop body is one region holding divergent branches, the compiler
+// structurizes all of it, and every case -- the plain Add as well -- leaves through a ladder of flag tests instead of
+// one jump to the loop's latch.  Out of line, every branch of the loop is a scalar branch and the switch stays a switch.
+__device__ __attribute__((noinline)) double xt_recip(double a) { return mr_recip(a); }
+__device__ __attribute__((noinline)) double xt_sqrt(double a) { return mr_sqrt(a); }
+__device__ __attribute__((noinline)) double xt_sin(double a) { return mr_sin(a); }
+__device__ __attribute__((noinline)) double xt_stepsin(double a) { return mr_stepsin(a); }
+__device__ __attribute__((noinline)) double xt_exp(double a) { return mr_exp(a); }
+__device__ __attribute__((noinline)) double xt_ln(double a) { return mr_ln(a); }
+__device__ __attribute__((noinline)) double xt_app(const MarayTex *tex, uint32_t id, double a, double b) { return mr_app(tex, id, a, b); }
+
 template <bool TAPE_LDS, int MODE>
 __device__ __forceinline__ void run_xtape(const KArgs &A, const uint64_t *xtape, uint32_t n_ops, const uint64_t *tape_lds, const double *consts_lds,
                                           double *slots, const Item &I, double &o0, double &o1, double &o2, uint32_t &gacc)
@@ -270,13 +282,13 @@ __device__ __forceinline__ void run_xtape(const KArgs &A, const uint64_t *xtape,
         UN3(X_UN + 3, mr_abs(a))
         UN3(X_UN + 6, mr_step(a))
         UN3(X_UN + 9, a)
-        case X_HEAVY + 0: r = mr_recip(FG(ib, ia)); break;
-        case X_HEAVY + 1: r = mr_sqrt(FG(ib, ia)); break;
-        case X_HEAVY + 2: r = mr_sin(FG(ib, ia)); break;
-        case X_HEAVY + 3: r = mr_stepsin(FG(ib, ia)); break;
-        case X_HEAVY + 4: r = mr_exp(FG(ib, ia)); break;
-        case X_HEAVY + 5: r = mr_ln(FG(ib, ia)); break;
-        BIN9(X_APP, mr_app(A.tex, aux, a, b))
+        case X_HEAVY + 0: r = xt_recip(FG(ib, ia)); break;
+        case X_HEAVY + 1: r = xt_sqrt(FG(ib, ia)); break;
+        case X_HEAVY + 2: r = xt_sin(FG(ib, ia)); break;
+        case X_HEAVY + 3: r = xt_stepsin(FG(ib, ia)); break;
+        case X_HEAVY + 4: r = xt_exp(FG(ib, ia)); break;
+        case X_HEAVY + 5: r = xt_ln(FG(ib, ia)); break;
+        BIN9(X_APP, xt_app(A.tex, aux, a, b))
         case X_TEXDIM: r = mr_texdim(A.tex, aux); break;
         case X_OUT + 0: case X_OUT + 1: case X_OUT + 2: {
             const double v = FG(op - X_OUT, ia);

@@ -515,7 +515,7 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
          "                                                                    const unsigned long long *__restrict__ gbits, unsigned n_tx,\n"
          "                                                                    unsigned w, unsigned y0, unsigned n_yvals, unsigned tiles,\n"
          "                                                                    unsigned blk_rows, unsigned blk_stride, unsigned row_base, unsigned yrows)\n{\n"
-         "    const unsigned r = blockIdx.y;                     // row of this launch; row_base + r = row of the whole call\n"
+         + std::string(getenv("MARAY_JIT_ROWS_REVERSED") ? "    const unsigned r = gridDim.y - 1u - blockIdx.y;\n" : "    const unsigned r = blockIdx.y;                     // row of this launch; row_base + r = row of the whole call\n") +
          "    const double *yrow = yvals + (size_t)r * n_yvals;\n";
     if (defer) s += "    if (threadIdx.x == 0) mr_slow_tile = 0u;\n";
     // every load of the prologue is issued before the first use: one memory latency, not one per round
