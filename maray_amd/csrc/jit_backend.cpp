@@ -515,6 +515,8 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
          "                                                                    const unsigned long long *__restrict__ gbits, unsigned n_tx,\n"
          "                                                                    unsigned w, unsigned y0, unsigned n_yvals, unsigned tiles,\n"
          "                                                                    unsigned blk_rows, unsigned blk_stride, unsigned row_base, unsigned yrows)\n{\n"
+         // MARAY_JIT_ROWS_REVERSED (ablation): last rows first.  For chess (board at the bottom) the dear blocks then start
+         // first and the launch's tail is sky: 71 -> 68 us per frame, i.e. the tail costs ~4 us.  Not general, not the default.
          + std::string(getenv("MARAY_JIT_ROWS_REVERSED") ? "    const unsigned r = gridDim.y - 1u - blockIdx.y;\n" : "    const unsigned r = blockIdx.y;                     // row of this launch; row_base + r = row of the whole call\n") +
          "    const double *yrow = yvals + (size_t)r * n_yvals;\n";
     if (defer) s += "    if (threadIdx.x == 0) mr_slow_tile = 0u;\n";
