@@ -259,46 +259,89 @@ __device__ __forceinline__ void run_xtape(const KArgs &A, const uint64_t *xtape,
         const uint32_t op = lo & 0x7Fu, aux = (lo >> 7) & 0x1FFFu, dst = lo >> 20;
         const uint32_t ia = hi & 0xFFFFu, ib = hi >> 16;
         double r;
-#define BIN9(BASE, EXPR)                                                                            \
-        case BASE + 0: { const double a = FS(ia), b = FS(ib); r = EXPR; break; }                    \
-        case BASE + 1: { const double a = FS(ia), b = acc; r = EXPR; break; }                       \
-        case BASE + 2: { const double a = FS(ia), b = FU(ib); r = EXPR; break; }                    \
-        case BASE + 3: { const double a = acc, b = FS(ib); r = EXPR; break; }                       \
-        case BASE + 4: { const double a = acc, b = acc; r = EXPR; break; }                          \
-        case BASE + 5: { const double a = acc, b = FU(ib); r = EXPR; break; }                       \
-        case BASE + 6: { const double a = FU(ia), b = FS(ib); r = EXPR; break; }                    \
-        case BASE + 7: { const double a = FU(ia), b = acc; r = EXPR; break; }                       \
-        case BASE + 8: { const double a = FU(ia), b = FU(ib); r = EXPR; break; }
-#define UN3(BASE, EXPR)                                                                             \
-        case BASE + 0: { const double a = FS(ia); r = EXPR; break; }                                \
-        case BASE + 1: { const double a = acc; r = EXPR; break; }                                   \
-        case BASE + 2: { const double a = FU(ia); r = EXPR; break; }
-        switch (op) {
-        BIN9(X_BIN + 0, a + b)
-        BIN9(X_BIN + 9, a * b)
-        BIN9(X_BIN + 18, mr_max(a, b))
-        BIN9(X_BIN + 27, mr_min(a, b))
-        UN3(X_UN + 0, mr_neg(a))
-        UN3(X_UN + 3, mr_abs(a))
-        UN3(X_UN + 6, mr_step(a))
-        UN3(X_UN + 9, a)
-        case X_HEAVY + 0: r = xt_recip(FG(ib, ia)); break;
-        case X_HEAVY + 1: r = xt_sqrt(FG(ib, ia)); break;
-        case X_HEAVY + 2: r = xt_sin(FG(ib, ia)); break;
-        case X_HEAVY + 3: r = xt_stepsin(FG(ib, ia)); break;
-        case X_HEAVY + 4: r = xt_exp(FG(ib, ia)); break;
-        case X_HEAVY + 5: r = xt_ln(FG(ib, ia)); break;
-        BIN9(X_APP, xt_app(A.tex, aux, a, b))
-        case X_TEXDIM: r = mr_texdim(A.tex, aux); break;
-        case X_OUT + 0: case X_OUT + 1: case X_OUT + 2: {
+        // Dispatch: a branch table.  The back end has no jump tables, a `switch` is a tree of six compare-and-branch
+        // levels, each on another line of the instruction cache; here the opcode indexes a table of s_branch
+        // instructions that follows the s_setpc (s_getpc returns the address of the instruction after itself: the
+        // table starts 12 bytes on, one 4-byte s_branch per opcode).
+        {
+            const uint32_t joff = (op < 93u ? op : 0u) * 4u + 12u;
+            asm goto("s_getpc_b64 s[20:21]\n\ts_add_u32 s20, s20, %0\n\ts_addc_u32 s21, s21, 0\n\ts_setpc_b64 s[20:21]"
+                     "\n\ts_branch %l1\n\ts_branch %l1\n\ts_branch %l1\n\ts_branch %l1\n\ts_branch %l1\n\ts_branch %l1\n\ts_branch %l1\n\ts_branch %l1\n\ts_branch %l1\n\ts_branch %l1\n\ts_branch %l1\n\ts_branch %l1\n\ts_branch %l1\n\ts_branch %l1\n\ts_branch %l1\n\ts_branch %l1\n\ts_branch %l2\n\ts_branch %l3\n\ts_branch %l4\n\ts_branch %l5\n\ts_branch %l6\n\ts_branch %l7\n\ts_branch %l8\n\ts_branch %l9\n\ts_branch %l10\n\ts_branch %l11\n\ts_branch %l12\n\ts_branch %l13\n\ts_branch %l14\n\ts_branch %l15\n\ts_branch %l16\n\ts_branch %l17\n\ts_branch %l18\n\ts_branch %l19\n\ts_branch %l20\n\ts_branch %l21\n\ts_branch %l22\n\ts_branch %l23\n\ts_branch %l24\n\ts_branch %l25\n\ts_branch %l26\n\ts_branch %l27\n\ts_branch %l28\n\ts_branch %l29\n\ts_branch %l30\n\ts_branch %l31\n\ts_branch %l32\n\ts_branch %l33\n\ts_branch %l34\n\ts_branch %l35\n\ts_branch %l36\n\ts_branch %l37\n\ts_branch %l38\n\ts_branch %l39\n\ts_branch %l40\n\ts_branch %l41\n\ts_branch %l42\n\ts_branch %l43\n\ts_branch %l44\n\ts_branch %l45\n\ts_branch %l46\n\ts_branch %l47\n\ts_branch %l48\n\ts_branch %l49\n\ts_branch %l50\n\ts_branch %l51\n\ts_branch %l52\n\ts_branch %l53\n\ts_branch %l54\n\ts_branch %l55\n\ts_branch %l1\n\ts_branch %l1\n\ts_branch %l56\n\ts_branch %l57\n\ts_branch %l58\n\ts_branch %l59\n\ts_branch %l60\n\ts_branch %l61\n\ts_branch %l62\n\ts_branch %l63\n\ts_branch %l64\n\ts_branch %l65\n\ts_branch %l66\n\ts_branch %l66\n\ts_branch %l66\n\ts_branch %l67\n\ts_branch %l67\n\ts_branch %l67\n\ts_branch %l67\n\ts_branch %l67\n\ts_branch %l67\n\ts_branch %l67\n\ts_branch %l67"
+                     : : "s"(joff) : "s20", "s21", "scc" : XL_NOP, XL_ADD0, XL_ADD1, XL_ADD2, XL_ADD3, XL_ADD4, XL_ADD5, XL_ADD6, XL_ADD7, XL_ADD8, XL_MUL0, XL_MUL1, XL_MUL2, XL_MUL3, XL_MUL4, XL_MUL5, XL_MUL6, XL_MUL7, XL_MUL8, XL_MAX0, XL_MAX1, XL_MAX2, XL_MAX3, XL_MAX4, XL_MAX5, XL_MAX6, XL_MAX7, XL_MAX8, XL_MIN0, XL_MIN1, XL_MIN2, XL_MIN3, XL_MIN4, XL_MIN5, XL_MIN6, XL_MIN7, XL_MIN8, XL_NEG0, XL_NEG1, XL_NEG2, XL_ABS0, XL_ABS1, XL_ABS2, XL_STEP0, XL_STEP1, XL_STEP2, XL_MOV0, XL_MOV1, XL_MOV2, XL_H0, XL_H1, XL_H2, XL_H3, XL_H4, XL_H5, XL_APP0, XL_APP1, XL_APP2, XL_APP3, XL_APP4, XL_APP5, XL_APP6, XL_APP7, XL_APP8, XL_TEXDIM, XL_OUT, XL_SKIP);
+            goto XL_NEXT;                                 // (not reached: the asm always jumps)
+        }
+        XL_ADD0: { const double a = FS(ia), b = FS(ib); r = a + b; goto XL_WRITE; }
+        XL_ADD1: { const double a = FS(ia), b = acc; r = a + b; goto XL_WRITE; }
+        XL_ADD2: { const double a = FS(ia), b = FU(ib); r = a + b; goto XL_WRITE; }
+        XL_ADD3: { const double a = acc, b = FS(ib); r = a + b; goto XL_WRITE; }
+        XL_ADD4: { const double a = acc, b = acc; r = a + b; goto XL_WRITE; }
+        XL_ADD5: { const double a = acc, b = FU(ib); r = a + b; goto XL_WRITE; }
+        XL_ADD6: { const double a = FU(ia), b = FS(ib); r = a + b; goto XL_WRITE; }
+        XL_ADD7: { const double a = FU(ia), b = acc; r = a + b; goto XL_WRITE; }
+        XL_ADD8: { const double a = FU(ia), b = FU(ib); r = a + b; goto XL_WRITE; }
+        XL_MUL0: { const double a = FS(ia), b = FS(ib); r = a * b; goto XL_WRITE; }
+        XL_MUL1: { const double a = FS(ia), b = acc; r = a * b; goto XL_WRITE; }
+        XL_MUL2: { const double a = FS(ia), b = FU(ib); r = a * b; goto XL_WRITE; }
+        XL_MUL3: { const double a = acc, b = FS(ib); r = a * b; goto XL_WRITE; }
+        XL_MUL4: { const double a = acc, b = acc; r = a * b; goto XL_WRITE; }
+        XL_MUL5: { const double a = acc, b = FU(ib); r = a * b; goto XL_WRITE; }
+        XL_MUL6: { const double a = FU(ia), b = FS(ib); r = a * b; goto XL_WRITE; }
+        XL_MUL7: { const double a = FU(ia), b = acc; r = a * b; goto XL_WRITE; }
+        XL_MUL8: { const double a = FU(ia), b = FU(ib); r = a * b; goto XL_WRITE; }
+        XL_MAX0: { const double a = FS(ia), b = FS(ib); r = mr_max(a, b); goto XL_WRITE; }
+        XL_MAX1: { const double a = FS(ia), b = acc; r = mr_max(a, b); goto XL_WRITE; }
+        XL_MAX2: { const double a = FS(ia), b = FU(ib); r = mr_max(a, b); goto XL_WRITE; }
+        XL_MAX3: { const double a = acc, b = FS(ib); r = mr_max(a, b); goto XL_WRITE; }
+        XL_MAX4: { const double a = acc, b = acc; r = mr_max(a, b); goto XL_WRITE; }
+        XL_MAX5: { const double a = acc, b = FU(ib); r = mr_max(a, b); goto XL_WRITE; }
+        XL_MAX6: { const double a = FU(ia), b = FS(ib); r = mr_max(a, b); goto XL_WRITE; }
+        XL_MAX7: { const double a = FU(ia), b = acc; r = mr_max(a, b); goto XL_WRITE; }
+        XL_MAX8: { const double a = FU(ia), b = FU(ib); r = mr_max(a, b); goto XL_WRITE; }
+        XL_MIN0: { const double a = FS(ia), b = FS(ib); r = mr_min(a, b); goto XL_WRITE; }
+        XL_MIN1: { const double a = FS(ia), b = acc; r = mr_min(a, b); goto XL_WRITE; }
+        XL_MIN2: { const double a = FS(ia), b = FU(ib); r = mr_min(a, b); goto XL_WRITE; }
+        XL_MIN3: { const double a = acc, b = FS(ib); r = mr_min(a, b); goto XL_WRITE; }
+        XL_MIN4: { const double a = acc, b = acc; r = mr_min(a, b); goto XL_WRITE; }
+        XL_MIN5: { const double a = acc, b = FU(ib); r = mr_min(a, b); goto XL_WRITE; }
+        XL_MIN6: { const double a = FU(ia), b = FS(ib); r = mr_min(a, b); goto XL_WRITE; }
+        XL_MIN7: { const double a = FU(ia), b = acc; r = mr_min(a, b); goto XL_WRITE; }
+        XL_MIN8: { const double a = FU(ia), b = FU(ib); r = mr_min(a, b); goto XL_WRITE; }
+        XL_NEG0: { const double a = FS(ia); r = mr_neg(a); goto XL_WRITE; }
+        XL_NEG1: { const double a = acc; r = mr_neg(a); goto XL_WRITE; }
+        XL_NEG2: { const double a = FU(ia); r = mr_neg(a); goto XL_WRITE; }
+        XL_ABS0: { const double a = FS(ia); r = mr_abs(a); goto XL_WRITE; }
+        XL_ABS1: { const double a = acc; r = mr_abs(a); goto XL_WRITE; }
+        XL_ABS2: { const double a = FU(ia); r = mr_abs(a); goto XL_WRITE; }
+        XL_STEP0: { const double a = FS(ia); r = mr_step(a); goto XL_WRITE; }
+        XL_STEP1: { const double a = acc; r = mr_step(a); goto XL_WRITE; }
+        XL_STEP2: { const double a = FU(ia); r = mr_step(a); goto XL_WRITE; }
+        XL_MOV0: { const double a = FS(ia); r = a; goto XL_WRITE; }
+        XL_MOV1: { const double a = acc; r = a; goto XL_WRITE; }
+        XL_MOV2: { const double a = FU(ia); r = a; goto XL_WRITE; }
+        XL_H0: r = xt_recip(FG(ib, ia)); goto XL_WRITE;
+        XL_H1: r = xt_sqrt(FG(ib, ia)); goto XL_WRITE;
+        XL_H2: r = xt_sin(FG(ib, ia)); goto XL_WRITE;
+        XL_H3: r = xt_stepsin(FG(ib, ia)); goto XL_WRITE;
+        XL_H4: r = xt_exp(FG(ib, ia)); goto XL_WRITE;
+        XL_H5: r = xt_ln(FG(ib, ia)); goto XL_WRITE;
+        XL_APP0: { const double a = FS(ia), b = FS(ib); r = xt_app(A.tex, aux, a, b); goto XL_WRITE; }
+        XL_APP1: { const double a = FS(ia), b = acc; r = xt_app(A.tex, aux, a, b); goto XL_WRITE; }
+        XL_APP2: { const double a = FS(ia), b = FU(ib); r = xt_app(A.tex, aux, a, b); goto XL_WRITE; }
+        XL_APP3: { const double a = acc, b = FS(ib); r = xt_app(A.tex, aux, a, b); goto XL_WRITE; }
+        XL_APP4: { const double a = acc, b = acc; r = xt_app(A.tex, aux, a, b); goto XL_WRITE; }
+        XL_APP5: { const double a = acc, b = FU(ib); r = xt_app(A.tex, aux, a, b); goto XL_WRITE; }
+        XL_APP6: { const double a = FU(ia), b = FS(ib); r = xt_app(A.tex, aux, a, b); goto XL_WRITE; }
+        XL_APP7: { const double a = FU(ia), b = acc; r = xt_app(A.tex, aux, a, b); goto XL_WRITE; }
+        XL_APP8: { const double a = FU(ia), b = FU(ib); r = xt_app(A.tex, aux, a, b); goto XL_WRITE; }
+        XL_TEXDIM: r = mr_texdim(A.tex, aux); goto XL_WRITE;
+        XL_OUT: {
             const double v = FG(op - X_OUT, ia);
             if (MODE == MODE_ROW) I.yout[aux] = v;
             else if (MODE == MODE_GUARDS) { if (v != 0.0) gacc |= 1u << ((aux - A.guard_first) & 7u); }
             else if (aux == 0) o0 = v; else if (aux == 1) o1 = v; else o2 = v;
-            continue;                                     // OUT leaves ACC and slots untouched
+            goto XL_NEXT;                                 // OUT leaves ACC and slots untouched
         }
-        case X_SKIPZ + XS: case X_SKIPZ + XA: case X_SKIPZ + XU: case X_SKIPZ + XG:
-        case X_SKIPNZ + XS: case X_SKIPNZ + XA: case X_SKIPNZ + XU: case X_SKIPNZ + XG: {
+        XL_SKIP: {
             const bool nz = op >= X_SKIPNZ;
             const uint32_t k = op - (nz ? X_SKIPNZ : X_SKIPZ);
             bool decided;
@@ -314,14 +357,13 @@ __device__ __forceinline__ void run_xtape(const KArgs &A, const uint64_t *xtape,
                 pc += aux;
                 if (AHEAD) ahead = tape_k[pc + 1 < n_ops ? pc + 1 : pc];
             }
-            continue;
+            goto XL_NEXT;
         }
-        default: continue;                                // NOP
-        }
-#undef BIN9
-#undef UN3
+        XL_NOP: goto XL_NEXT;
+    XL_WRITE:
         acc = r;
         FS(dst) = r;
+    XL_NEXT:;
     }
 #undef FS
 }
