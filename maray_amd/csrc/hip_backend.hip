@@ -846,7 +846,9 @@ struct TapeBackend final : Backend {
         const uint64_t tiles = (uint64_t)A.tiles_per_row * rows;
         if (tiles > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
         A.n_tiles = (uint32_t)tiles;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, (uint64_t)prop.multiProcessorCount * blocks_per_cu);
+        uint32_t per_cu = blocks_per_cu;
+        if (const char *e_ = getenv("MARAY_TAPE_BLOCKS_PER_CU")) if (atoi(e_) > 0) per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(e_));   // diagnosis: occupancy
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, (uint64_t)prop.multiProcessorCount * per_cu);
         if (P.n_pix_slots > n_lds_slots) {
             ensure(d_spill, spill_cap, std::max(spill_cap, (size_t)(P.n_pix_slots - n_lds_slots) * grid * BLOCK));
             A.spill = d_spill;
