@@ -481,14 +481,16 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
     std::string &s = E.out;
     s += "// generated by libmaray_hip (jit_backend.cpp) from a v" + std::to_string(P.version) + " tape: PIXEL section, " +
          std::to_string(P.n_pix_ops) + " ops\n";
-    // y values of the block's row: staged in LDS (broadcast ds_read_b128 into VGPRs) when they fit;
-    // as scalar loads they would park in SGPRs and spill through v_writelane / v_readlane.
+    // y values of the block's row: scalar loads from the row table where they are used.  (MARAY_JIT_YLDS=1 stages them
+    // in LDS at block start instead -- that paid while every region's y values were live at once and spilled through
+    // v_writelane; with guards per rectangle few are, and the staging only lengthens every block's prologue: chess
+    // 70.1 -> 66.3 us per frame, 300 triangles 0.34 -> 0.28 ms without it.)
     // tuning knobs (environment): MARAY_JIT_YLDS=0/1, MARAY_JIT_WAVES=<min waves per SIMD for __launch_bounds__>
     const char *env_ylds = getenv("MARAY_JIT_YLDS");
     const char *env_waves = getenv("MARAY_JIT_WAVES");
     const int min_waves = env_waves ? atoi(env_waves) : min_waves_arg;
     const uint32_t n_ynum = numeric_yvals(P);   // y values read as operands (a prefix of the table); the rest only gate SKIPs
-    const bool y_lds = n_ynum > 0 && n_ynum <= 4096 && !(env_ylds && env_ylds[0] == '0');
+    const bool y_lds = n_ynum > 0 && n_ynum <= 4096 && env_ylds && env_ylds[0] == '1';
     // SKIP ops whose guard is a y value (a bound of a boolean over a span of pixels): maray_jit_rows has evaluated the
     // guards for every rectangle of `yrows` rows x 256 pixels and packed them 64 per word; the block stages the words
     // of all its tiles in LDS, the words of the tile at hand sit in SGPRs and a region's test is one s_bitcmp1_b64.

@@ -308,11 +308,11 @@ def test_guards_per_group_of_rows_with_ragged_ranges(chess_bytes):
 
 
 def test_specialised_kernel_variants_selected_by_tuning_knobs(chess_bytes, monkeypatch):
-    """Paths the default build of chess does not take: y values read by scalar loads instead of from LDS (what a
-    program with more than 4096 operand y values gets), guards compiled away, one tile per block, literal constants."""
+    """Paths the default build of chess does not take: y values staged in LDS instead of read by scalar loads, guards
+    compiled away, one tile per block, literal constants."""
     g = json.load(open(os.path.join(GOLDEN, 'chess_1024.json')))
     tape = M.Scene(chess_bytes).lower()
-    for env in ({'MARAY_JIT_YLDS': '0'}, {'MARAY_JIT_ROW_GUARDS': '0'}, {'MARAY_JIT_TILES': '1'}, {'MARAY_JIT_KTAB': '0'},
+    for env in ({'MARAY_JIT_YLDS': '1'}, {'MARAY_JIT_ROW_GUARDS': '0'}, {'MARAY_JIT_TILES': '1'}, {'MARAY_JIT_KTAB': '0'},
                 {'MARAY_JIT_ROW_BLOCK': '64', 'MARAY_JIT_TILES': '3'}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
