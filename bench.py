@@ -41,8 +41,8 @@ BLOCK_ROWS = 64                    # rows are dealt to the ranks in blocks of th
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--backend', default=os.environ.get('MARAY_BENCH_BACKEND', 'auto'))
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='CPU baseline sample budget (0 = skip)')
     ap.add_argument('--cpu-jit', action='store_true', help='also time the JIT stand-in (scene compiled to native code by cc)')
