@@ -500,7 +500,11 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
     if (n_gwords) { E.guard_first = n_ynum; E.guard_words = n_gwords; }
     if (y_lds) E.yv_name = "mr_ylds";
     if (y_lds) s += "__shared__ double mr_ylds[" + std::to_string(n_ynum) + "];\n";
-    if (E.guard_words) s += "__shared__ unsigned long long mr_gq[" + std::to_string((E.guard_words <= 12 ? 16 : 8) * E.guard_words) + "];     // the guard words of the block's tiles\n";
+    // MARAY_JIT_GLDS=0: the guard words of a tile by scalar loads issued one tile ahead, instead of staging the words of
+    // all the block's tiles in LDS (vector load, ds_write, barrier, ds_read + v_readfirstlane per word and tile)
+    const char *env_glds = getenv("MARAY_JIT_GLDS");
+    const bool g_lds = E.guard_words > 12 || !(env_glds && env_glds[0] == '0');
+    if (E.guard_words && g_lds) s += "__shared__ unsigned long long mr_gq[" + std::to_string((E.guard_words <= 12 ? 16 : 8) * E.guard_words) + "];     // the guard words of the block's tiles\n";
     const bool defer = may_defer_tiles(P);
     s += "__shared__ unsigned mr_slow_tile;\n"
          "__device__ inline double mr_defer_sin(double) { mr_slow_tile = 1u; return 0.0; }\n"
@@ -534,20 +538,24 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
         const std::string nw = std::to_string(E.guard_words);
         s += "    const unsigned tile0 = blockIdx.x * tiles, my_tiles = n_tx - tile0 < tiles ? n_tx - tile0 : tiles;\n"
              "    const unsigned long long *gsrc = gbits + ((size_t)((row_base + r) / yrows) * n_tx + tile0) * " + nw + "u;\n"
-             "    const unsigned long long gs = threadIdx.x < my_tiles * " + nw + "u ? gsrc[threadIdx.x] : 0ull;\n";
+             + (g_lds ? "    const unsigned long long gs = threadIdx.x < my_tiles * " + nw + "u ? gsrc[threadIdx.x] : 0ull;\n"
+                      : std::string("    const __attribute__((address_space(4))) unsigned long long *mr_gk = (const __attribute__((address_space(4))) unsigned long long *)gsrc;\n"));
+        if (!g_lds)
+            for (uint32_t j = 0; j < E.guard_words; j++)
+                s += "    unsigned long long nq" + std::to_string(j) + " = mr_gk[" + std::to_string(j) + "u];\n";
     }
     for (uint32_t k = 0; k < y_rounds; k++) {
         const std::string i = std::to_string(k * 256) + "u + threadIdx.x";
         s += "    if (" + i + " < " + std::to_string(n_ynum) + "u) mr_ylds[" + i + "] = ys" + std::to_string(k) + ";\n";
     }
-    if (E.guard_words) {
+    if (E.guard_words && g_lds) {
         const std::string cap = std::to_string((E.guard_words <= 12 ? 16 : 8) * E.guard_words);
         s += "    if (threadIdx.x < " + cap + "u) mr_gq[threadIdx.x] = gs;\n";
         if ((E.guard_words <= 12 ? 16 : 8) * E.guard_words > 256)       // more words than threads: the rest in rounds
             s += "    for (unsigned i = 256u + threadIdx.x; i < my_tiles * " + std::to_string(E.guard_words) + "u; i += 256u) mr_gq[i] = gsrc[i];\n";
     }
-    s += "    __syncthreads();\n"
-         "    const double Y = (double)(y0 + ((row_base + r) / blk_rows) * blk_stride + (row_base + r) % blk_rows);     // -> image row (RowBlocks)\n"
+    if (y_lds || defer || (E.guard_words && g_lds)) s += "    __syncthreads();\n";
+    s += "    const double Y = (double)(y0 + ((row_base + r) / blk_rows) * blk_stride + (row_base + r) % blk_rows);     // -> image row (RowBlocks)\n"
          "    unsigned long long mr_ybase = (unsigned long long)yrow;\n"
          "    (void)Y; (void)tex; (void)gbits; (void)n_tx; (void)yrows;\n";
     s += "    const unsigned mr_lane = threadIdx.x & 63u;                              // dword mr_lane of a wave's RGB8 run starts\n"
@@ -561,7 +569,14 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
          "    (void)yv; (void)yw;\n"
          "/*MR_KBASE*/";
     if (E.guard_words) {
-        if (E.guard_words <= 12)
+        if (!g_lds) {
+            for (uint32_t j = 0; j < E.guard_words; j++)
+                s += "    const mr_mask gq" + std::to_string(j) + " = nq" + std::to_string(j) + ";\n";
+            s += "    { const unsigned tn = (t + 1u < my_tiles ? t + 1u : t) * " + std::to_string(E.guard_words) + "u;\n";
+            for (uint32_t j = 0; j < E.guard_words; j++)
+                s += "      nq" + std::to_string(j) + " = mr_gk[tn + " + std::to_string(j) + "u];\n";
+            s += "    }\n";
+        } else if (E.guard_words <= 12)
             for (uint32_t j = 0; j < E.guard_words; j++)
                 s += "    const mr_mask gq" + std::to_string(j) + " = mr_uniform64(mr_gq[t * " + std::to_string(E.guard_words) + "u + " + std::to_string(j) + "u]);\n";
         else
