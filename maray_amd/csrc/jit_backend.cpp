@@ -465,6 +465,29 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
              "    ((unsigned char *)gbits)[item * " + std::to_string(8 * n_gwords) + "u + (blockIdx.y - " + std::to_string(chunks.size()) + "u)] = (unsigned char)gacc;\n";
     }
     s += "}\n";
+    // Launch order of the PIXEL kernel: groups of rows by what they cost, dearest first, so that the tail of the launch is
+    // made of cheap blocks.  Cost of a group = set bits in the guard words of its rectangles (shapes that may show there).
+    // The bits are a function of the program and of the launch's geometry only: the order is computed once per geometry
+    // (one block; rank by counting) and reused.  Rows of a group stay neighbours (they share guard words and cache lines).
+    if (n_gwords)
+        s += "extern \"C\" __global__ void __launch_bounds__(256) maray_jit_order(const unsigned long long *__restrict__ gbits, unsigned *__restrict__ order,\n"
+             "                                                                  unsigned rows, unsigned n_tx, unsigned yrows)\n{\n"
+             "    extern __shared__ unsigned mr_cost[];\n"
+             "    const unsigned n_groups = (rows + yrows - 1u) / yrows, n_full = rows / yrows, per = n_tx * " + std::to_string(n_gwords) + "u;\n"
+             "    for (unsigned g = threadIdx.x; g < n_groups; g += 256u) {\n"
+             "        unsigned c = 0;\n"
+             "        for (unsigned i = 0; i < per; i++) c += (unsigned)__builtin_popcountll(gbits[(size_t)g * per + i]);\n"
+             "        mr_cost[g] = c;\n"
+             "    }\n"
+             "    __syncthreads();\n"
+             "    for (unsigned g = threadIdx.x; g < n_full; g += 256u) {\n"
+             "        const unsigned c = mr_cost[g];\n"
+             "        unsigned rank = 0;\n"
+             "        for (unsigned h = 0; h < n_full; h++) rank += (mr_cost[h] > c || (mr_cost[h] == c && h < g)) ? 1u : 0u;\n"
+             "        for (unsigned i = 0; i < yrows; i++) order[rank * yrows + i] = g * yrows + i;\n"
+             "    }\n"
+             "    for (unsigned r = n_full * yrows + threadIdx.x; r < rows; r += 256u) order[r] = r;      // a partial last group stays last\n"
+             "}\n";
     return s;
 }
 
@@ -520,10 +543,11 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
          "                                                                    unsigned *__restrict__ tile_list, unsigned tile_base,\n"
          "                                                                    const unsigned long long *__restrict__ gbits, unsigned n_tx,\n"
          "                                                                    unsigned w, unsigned y0, unsigned n_yvals, unsigned tiles,\n"
-         "                                                                    unsigned blk_rows, unsigned blk_stride, unsigned row_base, unsigned yrows)\n{\n"
+         "                                                                    unsigned blk_rows, unsigned blk_stride, unsigned row_base, unsigned yrows,\n"
+         "                                                                    const unsigned *__restrict__ row_order)\n{\n"
          // MARAY_JIT_ROWS_REVERSED (ablation): last rows first.  For chess (board at the bottom) the dear blocks then start
          // first and the launch's tail is sky: 71 -> 68 us per frame, i.e. the tail costs ~4 us.  Not general, not the default.
-         + std::string(getenv("MARAY_JIT_ROWS_REVERSED") ? "    const unsigned r = gridDim.y - 1u - blockIdx.y;\n" : "    const unsigned r = blockIdx.y;                     // row of this launch; row_base + r = row of the whole call\n") +
+         + std::string(getenv("MARAY_JIT_ROWS_REVERSED") ? "    const unsigned r = gridDim.y - 1u - blockIdx.y;\n" : "    const unsigned r = row_order ? row_order[blockIdx.y] : blockIdx.y;     // row of this launch (dearest groups of rows first); row_base + r = row of the whole call\n") +
          "    const double *yrow = yvals + (size_t)r * n_yvals;\n";
     if (defer) s += "    if (threadIdx.x == 0) mr_slow_tile = 0u;\n";
     // every load of the prologue is issued before the first use: one memory latency, not one per round
@@ -710,7 +734,9 @@ struct JitBackend final : Backend {
     int device = 0;
     maray_program P{};
     hipModule_t mod = nullptr, mod_rows = nullptr;
-    hipFunction_t f_rows = nullptr, f_pix = nullptr;
+    hipFunction_t f_rows = nullptr, f_pix = nullptr, f_order = nullptr;
+    unsigned *d_order = nullptr; size_t order_cap = 0;
+    uint64_t order_key[3] = {0, 0, 0};                     // the geometry d_order was computed for
     Backend *slow = nullptr;            // tape interpreter: evaluates the tiles the pixel kernel deferred
     unsigned *d_flags = nullptr; size_t flags_cap = 0;
     DevTex *d_tex = nullptr;
@@ -731,7 +757,7 @@ struct JitBackend final : Backend {
         (void)hipFree(d_flags);
         (void)hipFree(d_tex);
         for (auto p : d_tex_rgb) (void)hipFree(p);
-        (void)hipFree(d_gbits);
+        (void)hipFree(d_gbits); (void)hipFree(d_order);
         (void)hipFree(d_yvals); (void)hipFree(d_rgb8); (void)hipFree(d_rgb64);
         if (own_stream) (void)hipStreamDestroy(own_stream);
     }
@@ -767,6 +793,7 @@ struct JitBackend final : Backend {
             HIP_TRY(hipModuleLoadData(&mod_rows, code_rows.data()));
             HIP_TRY(hipModuleGetFunction(&f_rows, mod_rows, "maray_jit_rows"));
             n_gwords = jit_guard_words(prog);
+            if (n_gwords && !(getenv("MARAY_JIT_NO_ORDER") && getenv("MARAY_JIT_NO_ORDER")[0] == '1')) HIP_TRY(hipModuleGetFunction(&f_order, mod_rows, "maray_jit_order"));
             guard_rows = jit_guard_rows(prog);
 
         }
@@ -821,6 +848,19 @@ struct JitBackend final : Backend {
             void *args[] = {&d_yvals, &d_gbits, &d_tex, &yy0, &rr, &n_yvals, &ww, &n_tx_, &blk_rows, &blk_stride, &yrows};
             HIP_TRY(hipModuleLaunchKernel(f_rows, (unsigned)((items + bs - 1) / bs), n_row_chunks + n_gjobs, 1, bs, 1, 1, 0, st, args, nullptr));
         }
+        // launch order of the PIXEL kernel (maray_jit_order): once per geometry, from the guard bits the ROW kernel just wrote
+        const unsigned *row_order = nullptr;
+        if (f_order && rows_pass && n_gwords && rows_total <= 65535 && n_groups <= 4096 && n_groups > 1) {
+            const uint64_t key[3] = {((uint64_t)w << 32) | rows_total, ((uint64_t)y0 << 32) | blk_rows, ((uint64_t)blk_stride << 32) | yrows};
+            if (key[0] != order_key[0] || key[1] != order_key[1] || key[2] != order_key[2]) {
+                ensure(d_order, order_cap, (size_t)rows_total);
+                unsigned rr = rows_total, n_tx_ = (w + 255) / 256;
+                void *oargs[] = {&d_gbits, &d_order, &rr, &n_tx_, &yrows};
+                HIP_TRY(hipModuleLaunchKernel(f_order, 1, 1, 1, 256, 1, 1, n_groups * 4, st, oargs, nullptr));
+                order_key[0] = key[0]; order_key[1] = key[1]; order_key[2] = key[2];
+            }
+            row_order = d_order;
+        }
         const unsigned n_tx = (w + 255) / 256;
         const uint64_t n_tiles = (uint64_t)n_tx * rows_total;
         // tiles per block: amortise the per-block prologue, but rows cost what they show (sky: nothing, board: 5x the
@@ -841,7 +881,7 @@ struct JitBackend final : Backend {
             unsigned ww = w, yy0 = y0, tile_base = r0 * gx, row_base = r0;
             const unsigned long long *gb = d_gbits;              // indexed by the row of the whole call
             unsigned ntx = n_tx;
-            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles, &blk_rows, &blk_stride, &row_base, &yrows};
+            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles, &blk_rows, &blk_stride, &row_base, &yrows, &row_order};
             HIP_TRY(hipModuleLaunchKernel(f_pix, gx, rows, 1, 256, 1, 1, 0, st, args, nullptr));
         }
         if (has_sin) slow->render_flagged(w, rb, d8, d64, st, d_flags, d_yvals);   // no-op unless a tile was deferred
