@@ -313,7 +313,7 @@ def test_specialised_kernel_variants_selected_by_tuning_knobs(chess_bytes, monke
     g = json.load(open(os.path.join(GOLDEN, 'chess_1024.json')))
     tape = M.Scene(chess_bytes).lower()
     for env in ({'MARAY_JIT_YLDS': '1'}, {'MARAY_JIT_ROW_GUARDS': '0'}, {'MARAY_JIT_TILES': '1'}, {'MARAY_JIT_KTAB': '0'},
-                {'MARAY_JIT_ROW_BLOCK': '64', 'MARAY_JIT_TILES': '3'}, {'MARAY_JIT_GLDS': '0'}, {'MARAY_JIT_ROWS_REVERSED': '1'}):
+                {'MARAY_JIT_ROW_BLOCK': '64', 'MARAY_JIT_TILES': '3'}, {'MARAY_JIT_GLDS': '0'}, {'MARAY_JIT_ROWS_REVERSED': '1'}, {'MARAY_JIT_NO_ORDER': '1'}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         ctx = M.Context(tape, backend=M.BACKEND_JIT)

@@ -16,6 +16,7 @@ run MARAY_JIT_TILES=16
 run MARAY_JIT_KTAB=0
 run MARAY_JIT_YLDS=1
 run MARAY_JIT_GLDS=0
+run MARAY_JIT_NO_ORDER=1
 run MARAY_JIT_ROWS_REVERSED=1
 run MARAY_BENCH_BACKEND=tape-smem
 run MARAY_BENCH_BACKEND=tape-smem MARAY_TAPE_GENERIC=1
