@@ -135,13 +135,17 @@ enum {
     MARAY_BACKEND_TAPE = 0,      /* tape interpreter kernel: tape + constants staged in LDS */
     MARAY_BACKEND_TAPE_SMEM = 1, /* tape interpreter kernel: tape streamed through the scalar cache */
     MARAY_BACKEND_JIT = 2,       /* tape specialised to straight-line HIP via hiprtc (GPU analogue of src/wasm.rs) */
-    MARAY_BACKEND_AUTO = 3       /* JIT up to 25,000 pixel ops (beyond, hiprtc takes minutes); else, or if hiprtc cannot build the
-                                    scene, the scalar-cache tape interpreter */
+    MARAY_BACKEND_AUTO = 3       /* the specialised kernels when their code objects are in the cache (MARAY_CACHE_DIR) or when
+                                    building them (estimated from the tape's size) costs less than what they save over
+                                    hint_mpixels of rendering; else the scalar-cache tape interpreter, which needs no build */
 };
 
 typedef struct maray_ctx_opts {
     uint32_t backend;       /* MARAY_BACKEND_* */
-    uint32_t reserved[7];
+    uint32_t hint_mpixels;  /* MARAY_BACKEND_AUTO: how many megapixels (2^20 pixels, rounded up) the caller is about to render with
+                               this context; 0 = unknown / many.  The specialised kernels are worth their hiprtc build only
+                               when that time is earned back (or when the code object cache already holds them). */
+    uint32_t reserved[6];
 } maray_ctx_opts;
 
 int maray_hip_device_count(int *n);
@@ -157,6 +161,23 @@ void maray_hip_ctx_free(maray_ctx *c);
  * Host-pointer form (device -> host copy included). */
 int maray_hip_render_rows(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
                           uint8_t *rgb8, double *rgb64);
+/* Several row ranges ("tiles", rows [y0,y1) each, given as n_tiles pairs y0,y1), rendered in the given order into ONE
+ * caller-owned RGB8 raster of the whole image (rgb8_image = first byte of image row 0; w*h*3 bytes).  This is what
+ * one worker of a multi-GPU render calls for its share of the image (the host-side gather of SURVEY.md 8(e), the
+ * collector thread of src/render.rs:54-83): tile k's device -> host copy runs under tile k+1's kernels, the call
+ * joins at the end.  fn (may be NULL) is called on the calling thread after each tile's rows have landed.
+ * A raster in pinned memory (maray_host_alloc / maray_host_register) is written by DMA directly at PCIe rate; a
+ * pageable one is filled through a pinned staging ring of the context (an extra host copy). */
+typedef void (*maray_tile_fn)(void *user, uint32_t y0, uint32_t y1);
+int maray_hip_render_tiles(maray_ctx *c, uint32_t w, uint32_t h, const uint32_t *tiles_y0y1, uint32_t n_tiles,
+                           uint8_t *rgb8_image, maray_tile_fn fn, void *user);
+/* Pinned (page-locked, DMA-able from every device) host memory for output rasters: what backs the `RgbImage` a
+ * caller hands to gen_to_image (src/lib.rs:1210) when it wants the PCIe rate.  maray_host_register pins memory the
+ * caller already owns (e.g. a Rust Vec<u8>) for the time between the two calls. */
+int maray_host_alloc(size_t bytes, void **out);
+void maray_host_free(void *p);
+int maray_host_register(void *p, size_t bytes);
+int maray_host_unregister(void *p);
 /* Device-pointer form: outputs stay in HBM; enqueued on `stream`
  * (a hipStream_t, NULL = the null stream); returns without synchronising. */
 int maray_hip_render_rows_device(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
@@ -183,6 +204,12 @@ int maray_jit_source(const maray_program *prog, char **src_out);
  * ROW section was cut into, evaluated side by side as blockIdx.y; may be NULL). */
 int maray_jit_source_rows(const maray_program *prog, char **src_out, uint32_t *n_chunks);
 int maray_jit_build(const maray_program *prog, void **code_out, size_t *len_out);
+/* The specialised kernels of a program are built once and kept, in the process and under MARAY_CACHE_DIR (default
+ * $XDG_CACHE_HOME/maray_amd or ~/.cache/maray_amd; "off" disables): the reference's JIT compiles its modules again on
+ * every thread of every render (src/render.rs:158-165).  The key is a 128-bit hash of the generated sources, the
+ * compiler options and the hiprtc version: 32 hex digits + NUL into out33.  Needs no GPU. */
+int maray_jit_code_key(const maray_program *prog, char *out33);
+int maray_jit_code_cached(const maray_program *prog, int *cached);
 /* Name of the dominant kernel (for matching rocprofv3 rows). */
 const char *maray_hip_kernel_name(const maray_ctx *c);
 

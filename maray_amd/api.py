@@ -44,7 +44,7 @@ class LowerOpts(C.Structure):
 
 
 class CtxOpts(C.Structure):
-    _fields_ = [('backend', C.c_uint32), ('reserved', C.c_uint32 * 7)]
+    _fields_ = [('backend', C.c_uint32), ('hint_mpixels', C.c_uint32), ('reserved', C.c_uint32 * 6)]
 
 
 class GenOpts(C.Structure):
@@ -57,6 +57,7 @@ class Report(C.Structure):
 
 
 REPORT_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.c_double)
+TILE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32)
 
 _lib = None
 
@@ -99,10 +100,17 @@ def lib():
                                            C.POINTER(vp)]),
         'maray_hip_ctx_free': (None, [vp]),
         'maray_hip_render_rows': (C.c_int, [vp, u32, u32, u32, u32, vp, vp]),
+        'maray_hip_render_tiles': (C.c_int, [vp, u32, u32, C.POINTER(u32), u32, vp, TILE_FN, vp]),
+        'maray_host_alloc': (C.c_int, [C.c_size_t, C.POINTER(vp)]),
+        'maray_host_free': (None, [vp]),
+        'maray_host_register': (C.c_int, [vp, C.c_size_t]),
+        'maray_host_unregister': (C.c_int, [vp]),
         'maray_hip_render_rows_device': (C.c_int, [vp, u32, u32, u32, u32, vp, vp, vp]),
         'maray_hip_render_blocks_device': (C.c_int, [vp, u32, u32, u32, u32, u32, u32, vp, vp, vp]),
         'maray_hip_time_rows': (C.c_int, [vp, u32, u32, u32, u32, vp, vp, C.c_int, C.POINTER(C.c_float)]),
         'maray_hip_kernel_name': (C.c_char_p, [vp]),
+        'maray_jit_code_key': (C.c_int, [C.POINTER(Program), C.c_char_p]),
+        'maray_jit_code_cached': (C.c_int, [C.POINTER(Program), C.POINTER(C.c_int)]),
         'maray_gen_to_image': (C.c_int, [vp, C.POINTER(Texture), u32, C.POINTER(GenOpts), Report, REPORT_FN, vp, vp,
                                          u32, u32]),
         'maray_gen': (C.c_int, [vp, C.POINTER(Texture), u32, C.POINTER(GenOpts), Report, C.c_char_p]),
@@ -241,6 +249,19 @@ class Tape:
             lib().maray_tape_free(self._h)
             self._h = None
 
+    @property
+    def jit_code_key(self):
+        """Cache key of this program's specialised kernels (generated sources + options + hiprtc version)."""
+        buf = C.create_string_buffer(33)
+        _check(lib().maray_jit_code_key(C.byref(self.program), buf))
+        return buf.value.decode()
+
+    @property
+    def jit_code_cached(self):
+        v = C.c_int()
+        _check(lib().maray_jit_code_cached(C.byref(self.program), C.byref(v)))
+        return bool(v.value)
+
     def arrays(self):
         """(consts, row_ops, pix_ops) as numpy copies."""
         p = self.program
@@ -250,13 +271,34 @@ class Tape:
         return consts, row, pix
 
 
+class PinnedRaster:
+    """An (h, w, 3) uint8 raster in pinned host memory (maray_host_alloc): what a caller that wants the PCIe rate
+    hands to the render entry points; `.array` is a numpy view of it, valid until close()."""
+
+    def __init__(self, h, w):
+        p = C.c_void_p()
+        _check(lib().maray_host_alloc(h * w * 3, C.byref(p)))
+        self._p = p
+        self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(h, w, 3))
+
+    def close(self):
+        if getattr(self, '_p', None):
+            self.array = None
+            lib().maray_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        self.close()
+
+
 class Context:
     """Device context: tape + constants + textures resident in HBM."""
 
-    def __init__(self, tape, textures=None, device=0, backend=BACKEND_TAPE):
+    def __init__(self, tape, textures=None, device=0, backend=BACKEND_TAPE, hint_mpixels=0):
         arr, n, keep = _textures(textures)
         o = CtxOpts()
         o.backend = backend
+        o.hint_mpixels = hint_mpixels
         h = C.c_void_p()
         _check(lib().maray_hip_ctx_create(device, C.byref(tape.program), arr, n, C.byref(o), C.byref(h)))
         self._h = h
@@ -278,6 +320,18 @@ class Context:
                                            rgb64.ctypes.data if want_f64 else None))
         return rgb8, rgb64
 
+    def render_rows_into(self, w, h, y0, y1, rgb8):
+        """Rows [y0, y1) into the caller's (y1-y0, w, 3) uint8 array (pinned or pageable)."""
+        assert rgb8.dtype == np.uint8 and rgb8.flags['C_CONTIGUOUS'] and rgb8.size == (y1 - y0) * w * 3
+        _check(lib().maray_hip_render_rows(self._h, w, h, y0, y1, rgb8.ctypes.data, None))
+
+    def render_tiles(self, w, h, tiles, image, on_tile=None):
+        """Row ranges [(y0, y1), ...] into one (h, w, 3) uint8 raster of the whole image, pipelined (maray_hip_render_tiles)."""
+        assert image.dtype == np.uint8 and image.flags['C_CONTIGUOUS'] and image.size == h * w * 3
+        flat = (C.c_uint32 * (2 * len(tiles)))(*[v for t in tiles for v in t])
+        cb = TILE_FN((lambda user, a, b: on_tile(a, b)) if on_tile else 0)
+        _check(lib().maray_hip_render_tiles(self._h, w, h, flat, len(tiles), image.ctypes.data, cb, None))
+
     def render_rows_device(self, w, h, y0, y1, d_rgb8=0, d_rgb64=0, stream=0):
         _check(lib().maray_hip_render_rows_device(self._h, w, h, y0, y1, d_rgb8 or None, d_rgb64 or None, stream or None))
 
@@ -297,10 +351,11 @@ class Context:
 
 
 def gen_to_image(scene, size=None, textures=None, backend=BACKEND_AUTO, n_devices=0, tile_rows=0, report=None,
-                 report_kind=REPORT_NONE, report_value=0):
-    """`gen_to_image` (src/lib.rs:1177-1195) with RenderMethod::Hip → HxWx3 uint8."""
+                 report_kind=REPORT_NONE, report_value=0, out=None):
+    """`gen_to_image` (src/lib.rs:1177-1195) with RenderMethod::Hip → HxWx3 uint8 (into `out` when given)."""
     w, h = size if size else scene.size
-    img = np.zeros((h, w, 3), np.uint8)
+    img = np.zeros((h, w, 3), np.uint8) if out is None else out
+    assert img.shape == (h, w, 3) and img.dtype == np.uint8 and img.flags['C_CONTIGUOUS']
     arr, n, keep = _textures(textures)
     go = GenOpts()
     go.backend, go.n_devices, go.tile_rows = backend, n_devices, tile_rows

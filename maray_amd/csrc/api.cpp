@@ -3,6 +3,7 @@
 // never lets an exception cross the ABI.
 #include <pthread.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -85,6 +86,7 @@ void validate_program(const maray_program &p)
     if ((p.n_consts && !p.consts) || (p.n_row_ops && !p.row_ops) || (p.n_pix_ops && !p.pix_ops))
         throw Error{MARAY_E_ARG, "null section pointer"};
     if (p.n_row_slots > MARAY_MAX_SLOTS || p.n_pix_slots > MARAY_MAX_SLOTS) throw Error{MARAY_E_LIMIT, "too many slots"};
+    const uint32_t n_ynum = numeric_yvals(p);       // y values past these only gate SKIP ops (guards)
     auto check = [&](const uint64_t *ops, uint32_t n, uint32_t n_slots, bool pixel) {
         std::vector<uint8_t> written(n_slots, 0);
         bool have_acc = false;
@@ -127,6 +129,10 @@ void validate_program(const maray_program &p)
                 if (aux == 0 || (uint64_t)i + aux >= n) throw Error{MARAY_E_ARG, "skip count out of range at op " + std::to_string(i)};
                 if (!regions.empty() && i + aux > regions.back().end) throw Error{MARAY_E_ARG, "skip regions overlap at op " + std::to_string(i)};
                 if (dst != MARAY_DST_NONE && dst >= n_slots) throw Error{MARAY_E_ARG, "dst slot out of range at op " + std::to_string(i)};
+                // a guard (a y value nothing reads as an operand) is a bound, "0 => the boolean is 0 over the span": the
+                // evaluators keep it as one bit (!= 0) or do not keep its value at all; it can gate a SKIPZ only
+                if (op == MARAY_OP_SKIPNZ && MARAY_REF_KIND(refs[0]) == MARAY_K_YVAL && MARAY_REF_INDEX(refs[0]) >= n_ynum)
+                    throw Error{MARAY_E_ARG, "SKIPNZ on a guard y value at op " + std::to_string(i) + " (guards gate SKIPZ only)"};
                 const uint32_t last = MARAY_INS_OP(ops[i + aux]);
                 if (!(last == MARAY_OP_MUL || last == MARAY_OP_MIN || last == MARAY_OP_MAX))
                     throw Error{MARAY_E_ARG, "skip region must end in Mul / Min / Max at op " + std::to_string(i)};
@@ -307,16 +313,32 @@ int maray_hip_ctx_create(int device, const maray_program *prog, const maray_text
         case MARAY_BACKEND_TAPE: b = make_tape_backend(device, *prog, tex, n_tex, true); break;
         case MARAY_BACKEND_TAPE_SMEM: b = make_tape_backend(device, *prog, tex, n_tex, false); break;
         case MARAY_BACKEND_JIT: b = make_jit_backend(device, *prog, tex, n_tex); break;
-        case MARAY_BACKEND_AUTO:
-            // the specialised kernel pays for itself in hiprtc time: seconds up to ~10^4 pixel ops, minutes beyond
-            // (a 49 k-op scene took 6.5 min to build); larger programs start on the interpreter, which needs none
-            if (prog->n_pix_ops > 25000) { b = make_tape_backend(device, *prog, tex, n_tex, false); break; }
+        case MARAY_BACKEND_AUTO: {
+            // One-shot economics.  The specialised kernels render a frame tens of times faster than the interpreter, but
+            // hiprtc needs seconds to build them (chess: 10 k pixel + 17 k row ops -> 8 s; a 49 k-op scene took 6.5 min),
+            // the interpreter needs none.  So: take them when the code objects are already in the cache, or when the
+            // caller says how much it will render (hint_mpixels) and the interpreter would need longer for that than
+            // the build takes, or when it does not say (a context kept for many frames).  Estimates, measured on chess
+            // and the triangle soups: build 0.5 s + 0.4 ms per pixel op + 0.24 ms per row op;
+            // interpreter 4.4 us per megapixel and executed op, of which guards skip ~95 % when the program has any.
+            const char *force = getenv("MARAY_AUTO");          // "jit" / "tape": override (measurements)
+            bool want_jit = prog->n_pix_ops <= 25000;
+            if (want_jit && opts && opts->hint_mpixels && !jit_code_is_cached(*prog)) {
+                const double build_s = 0.5 + 4.0e-4 * prog->n_pix_ops + 2.4e-4 * prog->n_row_ops;
+                const bool guarded = prog->n_yvals > numeric_yvals(*prog);
+                const double interp_s = (double)opts->hint_mpixels * prog->n_pix_ops * 4.4e-6 * (guarded ? 0.05 : 1.0);
+                want_jit = interp_s > build_s;
+            }
+            if (force && !strcmp(force, "jit")) want_jit = true;
+            if (force && !strcmp(force, "tape")) want_jit = false;
+            if (!want_jit) { b = make_tape_backend(device, *prog, tex, n_tex, false); break; }
             try { b = make_jit_backend(device, *prog, tex, n_tex); }
             catch (const Error &e) {
                 if (e.code == MARAY_E_NO_DEVICE) throw;
                 b = make_tape_backend(device, *prog, tex, n_tex, false);   // still the HIP path, never a CPU fallback
             }
             break;
+        }
         default: throw Error{MARAY_E_ARG, "unknown backend"};
         }
         maray_ctx *c = new maray_ctx();
@@ -347,8 +369,47 @@ int maray_hip_render_rows(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uin
         REQUIRE(c && c->backend, "null context");
         check_rows(w, h, y0, y1);
         if (y0 == y1 || w == 0 || (!rgb8 && !rgb64)) return;
-        c->backend->render_host(w, h, y0, y1, rgb8, rgb64);
+        c->backend->render_host_tiles(w, h, cut_row_tiles(w, y0, y1, rgb8 != nullptr, rgb64 != nullptr), y0, rgb8, rgb64, nullptr);
     });
+}
+
+int maray_hip_render_tiles(maray_ctx *c, uint32_t w, uint32_t h, const uint32_t *tiles_y0y1, uint32_t n_tiles,
+                           uint8_t *rgb8_image, maray_tile_fn fn, void *user)
+{
+    return guard([&] {
+        REQUIRE(c && c->backend, "null context");
+        REQUIRE(n_tiles == 0 || tiles_y0y1, "null tile list");
+        if (n_tiles == 0 || w == 0 || !rgb8_image) return;
+        std::vector<RowTile> tiles(n_tiles);
+        for (uint32_t i = 0; i < n_tiles; i++) {
+            tiles[i] = RowTile{tiles_y0y1[2 * i], tiles_y0y1[2 * i + 1]};
+            check_rows(w, h, tiles[i].y0, tiles[i].y1);
+            REQUIRE(tiles[i].y1 > tiles[i].y0, "empty tile");
+        }
+        std::function<void(uint32_t, uint32_t)> done;
+        if (fn) done = [&](uint32_t a, uint32_t b) { fn(user, a, b); };
+        c->backend->render_host_tiles(w, h, tiles, 0, rgb8_image, nullptr, done);
+    });
+}
+
+int maray_host_alloc(size_t bytes, void **out)
+{
+    return guard([&] {
+        REQUIRE(out, "null argument");
+        *out = host_alloc_pinned(bytes);
+    });
+}
+
+void maray_host_free(void *p) { host_free_pinned(p); }
+
+int maray_host_register(void *p, size_t bytes)
+{
+    return guard([&] { REQUIRE(p && bytes, "null argument"); host_register(p, bytes); });
+}
+
+int maray_host_unregister(void *p)
+{
+    return guard([&] { REQUIRE(p, "null argument"); host_unregister(p); });
 }
 
 int maray_hip_render_rows_device(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
@@ -433,15 +494,28 @@ int maray_jit_build(const maray_program *prog, void **code_out, size_t *len_out)
 {
     return guard([&] {
         REQUIRE(prog && code_out && len_out, "null argument");
-        std::vector<char> code;
-        std::string log;
-        if (prog->n_row_ops) jit_compile(jit_source_rows(*prog), code, log);      // must build too; its code object is not returned
-        jit_compile(jit_source(*prog), code, log);
+        // both kernels, through the code object cache (this is also how a cache is warmed ahead of a render)
+        const std::vector<char> &code = jit_code_for(*prog)->pix;
         *code_out = malloc(code.size() ? code.size() : 1);
         if (!*code_out) throw Error{MARAY_E_INTERNAL, "out of memory"};
         memcpy(*code_out, code.data(), code.size());
         *len_out = code.size();
     });
+}
+
+int maray_jit_code_key(const maray_program *prog, char *out33)
+{
+    return guard([&] {
+        REQUIRE(prog && out33, "null argument");
+        const std::string k = jit_code_key(*prog);
+        memcpy(out33, k.c_str(), std::min<size_t>(k.size(), 32) + 1);
+        out33[32] = 0;
+    });
+}
+
+int maray_jit_code_cached(const maray_program *prog, int *cached)
+{
+    return guard([&] { REQUIRE(prog && cached, "null argument"); *cached = jit_code_is_cached(*prog) ? 1 : 0; });
 }
 
 const char *maray_hip_kernel_name(const maray_ctx *c) { return (c && c->backend) ? c->backend->kernel_name() : ""; }

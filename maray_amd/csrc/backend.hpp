@@ -3,6 +3,8 @@
 
 #include <array>
 #include <cstdint>
+#include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -19,12 +21,17 @@ struct RowBlocks {
     static RowBlocks range(uint32_t y0, uint32_t y1) { return RowBlocks{y0, y1 - y0, y1 > y0 ? y1 - y0 : 1u, 0u}; }
 };
 
+struct RowTile { uint32_t y0, y1; };      // rows [y0, y1)
+
 struct Backend {
     virtual ~Backend() {}
     // the rows of `rb` into device buffers, enqueued on `stream`, no synchronisation
     virtual void render_device(uint32_t w, uint32_t h, const RowBlocks &rb, void *d8, void *d64, void *stream) = 0;
-    // rows [y0,y1) into host buffers (blocking)
-    virtual void render_host(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint8_t *rgb8, double *rgb64) = 0;
+    // The row tiles, in order, into host rasters whose first byte is image row `row0` (blocking; either raster may
+    // be null).  Tile k's device -> host copy runs under tile k + 1's kernels (host_pipe.hpp); `done` (may be empty)
+    // is called on this thread once a tile's rows are in the raster.
+    virtual void render_host_tiles(uint32_t w, uint32_t h, const std::vector<RowTile> &tiles, uint32_t row0, uint8_t *rgb8, double *rgb64,
+                                   const std::function<void(uint32_t, uint32_t)> &done) = 0;
     // average ms per launch of the pixel kernel, HIP events on the launch stream
     virtual float time_rows(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, void *d8, void *d64, int reps) = 0;
     virtual const char *kernel_name() const = 0;
@@ -36,13 +43,31 @@ struct Backend {
     }
 };
 
+// host_pipe.cpp: rows [y0, y1) of a w-wide image cut into tiles of a few MiB of output; pinned host memory
+std::vector<RowTile> cut_row_tiles(uint32_t w, uint32_t y0, uint32_t y1, bool want8, bool want64);
+void *host_alloc_pinned(size_t bytes);          // throws Error
+void host_free_pinned(void *p);
+void host_register(void *p, size_t bytes);      // throws Error
+void host_unregister(void *p);                  // throws Error
+bool host_range_is_pinned(const void *p, size_t n);
+
 void set_last_error(const std::string &m);   // thread-local message behind maray_last_error()
 int hip_device_count();
 Backend *make_tape_backend(int device, const maray_program &prog, const maray_texture *tex, uint32_t n_tex, bool lds_variant);
 Backend *make_jit_backend(int device, const maray_program &prog, const maray_texture *tex, uint32_t n_tex);
-std::string jit_source(const maray_program &prog, int min_waves = 8);   // PIXEL kernel source (__launch_bounds__(256, min_waves)); throws Error
+std::string jit_source(const maray_program &prog, int min_waves = 0);   // PIXEL kernel source (__launch_bounds__(256, min_waves); 0 = the layout's default); throws Error
 std::string jit_source_rows(const maray_program &prog, uint32_t *n_chunks_out = nullptr, uint32_t *n_gjobs_out = nullptr);   // ROW kernel source (blockIdx.y = chunk)
 void jit_compile(const std::string &src, std::vector<char> &code, std::string &log);     // hiprtc, gfx950; throws Error
+// The two code objects of a program (jit_backend.cpp): built once per process, kept on disk under MARAY_CACHE_DIR.
+struct JitCode {
+    std::vector<char> pix, rows;        // maray_jit_pixels; maray_jit_rows + maray_jit_order (empty without a ROW section)
+    uint32_t n_row_chunks = 1, n_gjobs = 0;
+    int waves = 8;                      // the __launch_bounds__ occupancy the PIXEL kernel was built for
+    bool from_disk = false;
+};
+std::shared_ptr<const JitCode> jit_code_for(const maray_program &prog);      // needs no GPU; throws Error
+std::string jit_code_key(const maray_program &prog);                        // 128-bit hash (hex) of generated sources + toolchain: the cache's file name
+bool jit_code_is_cached(const maray_program &prog);                         // in this process or on disk: no hiprtc build needed
 void validate_program(const maray_program &p);
 
 // ---- ROW-tape analysis shared by the evaluators (row_split.cpp) ------------------------------------

@@ -31,8 +31,8 @@ MARAY_DEV mr_mask mr_uniform64(mr_mask v)
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return ((mr_mask)hi << 32) | lo;
 }
-#define mr_pos(m) mr_mask_f64(m, 0x3ff00000u, 0u)              /* +1.0 : +0.0 */
-#define mr_neg01(m) mr_mask_f64(m, 0xbff00000u, 0x80000000u)   /* -1.0 : -0.0 */
+MARAY_DEV double mr_pos(mr_mask m) { return mr_mask_f64(m, 0x3ff00000u, 0u); }               /* +1.0 : +0.0 */
+MARAY_DEV double mr_neg01(mr_mask m) { return mr_mask_f64(m, 0xbff00000u, 0x80000000u); }    /* -1.0 : -0.0 */
 
 // Neg Abs Recip Sqrt: IEEE-754 exact (:640-643).  1.0/a and sqrt lower to the
 // correctly rounded f64 expansions (no fast-math).
@@ -56,6 +56,13 @@ MARAY_DEV bool mr_stepsin_bounded_b(double a) { return maray_libm_step_sin_bound
 MARAY_DEV double mr_sin_bounded(double a) { return maray_libm_sin_bounded(a); }
 MARAY_DEV double mr_exp(double a) { return maray_libm_exp(a); }
 MARAY_DEV double mr_ln(double a) { return maray_libm_log(a); }
+
+// value -> lane mask, and the one test a region needs: is any lane's bit set
+MARAY_DEV mr_mask mr_ge0(double a) { return mr_ballot(a >= 0.0); }       // Step
+MARAY_DEV mr_mask mr_ne0(double a) { return mr_ballot(a != 0.0); }
+MARAY_DEV mr_mask mr_ne1(double a) { return mr_ballot(a != 1.0); }
+MARAY_DEV mr_mask mr_stepsin_bounded_m(double a) { return mr_ballot(maray_libm_step_sin_bounded(a) != 0.0); }
+MARAY_DEV bool mr_any(mr_mask m) { return m != MR_NONE; }
 
 // Rust `f64 as u8` (src/render.rs:92-94): saturating, NaN -> 0, truncation.
 MARAY_DEV unsigned mr_cast_u8(double v)
@@ -95,3 +102,57 @@ MARAY_DEV double mr_texdim(const MarayTex *tex, unsigned id)
     const MarayTex t = tex[id / 5u];
     return (id % 5u) == 3u ? (double)t.w : (double)t.h;
 }
+
+#ifdef MR_VEC4
+// ---- four pixels per lane (the specialised PIXEL kernel) --------------------------------------------------------
+// A wavefront owns a whole 256-pixel tile: every value is four f64 per lane (mr_d), every boolean four lane masks
+// (mr_m).  The scalar unit's work per tile -- guard-bit tests, region branches, constant and y-value loads -- is
+// then paid once per 256 pixels instead of once per 64, a lane's four RGB8 pixels are 12 contiguous bytes (one
+// global_store_dwordx3, no cross-lane packing), and four independent dependence chains are in flight per wave.
+// Element e of lane l is pixel x0 + 4 l + e (RGB8 only) or x0 + 64 e + l (when f64 planes are stored too).
+// Plain structs with element-wise operators: the same generated text serves both widths.
+struct mr_d {
+    double a, b, c, d;
+    MARAY_DEV mr_d() {}
+    MARAY_DEV mr_d(double s) : a(s), b(s), c(s), d(s) {}
+    MARAY_DEV mr_d(double a_, double b_, double c_, double d_) : a(a_), b(b_), c(c_), d(d_) {}
+};
+struct mr_m {
+    mr_mask a, b, c, d;
+    MARAY_DEV mr_m() {}
+    MARAY_DEV mr_m(mr_mask s) : a(s), b(s), c(s), d(s) {}
+    MARAY_DEV mr_m(mr_mask a_, mr_mask b_, mr_mask c_, mr_mask d_) : a(a_), b(b_), c(c_), d(d_) {}
+};
+#define MR_EACH1(f, v) mr_d(f((v).a), f((v).b), f((v).c), f((v).d))
+MARAY_DEV mr_d operator+(const mr_d &x, const mr_d &y) { return mr_d(x.a + y.a, x.b + y.b, x.c + y.c, x.d + y.d); }
+MARAY_DEV mr_d operator*(const mr_d &x, const mr_d &y) { return mr_d(x.a * y.a, x.b * y.b, x.c * y.c, x.d * y.d); }
+MARAY_DEV mr_m operator&(const mr_m &x, const mr_m &y) { return mr_m(x.a & y.a, x.b & y.b, x.c & y.c, x.d & y.d); }
+MARAY_DEV mr_m operator|(const mr_m &x, const mr_m &y) { return mr_m(x.a | y.a, x.b | y.b, x.c | y.c, x.d | y.d); }
+MARAY_DEV mr_m operator~(const mr_m &x) { return mr_m(~x.a, ~x.b, ~x.c, ~x.d); }
+MARAY_DEV bool mr_any(const mr_m &m) { return (m.a | m.b | m.c | m.d) != MR_NONE; }
+MARAY_DEV mr_d mr_pos(const mr_m &m) { return mr_d(mr_pos(m.a), mr_pos(m.b), mr_pos(m.c), mr_pos(m.d)); }
+MARAY_DEV mr_d mr_neg01(const mr_m &m) { return mr_d(mr_neg01(m.a), mr_neg01(m.b), mr_neg01(m.c), mr_neg01(m.d)); }
+MARAY_DEV mr_m mr_ge0(const mr_d &v) { return mr_m(mr_ge0(v.a), mr_ge0(v.b), mr_ge0(v.c), mr_ge0(v.d)); }
+MARAY_DEV mr_m mr_ne0(const mr_d &v) { return mr_m(mr_ne0(v.a), mr_ne0(v.b), mr_ne0(v.c), mr_ne0(v.d)); }
+MARAY_DEV mr_m mr_ne1(const mr_d &v) { return mr_m(mr_ne1(v.a), mr_ne1(v.b), mr_ne1(v.c), mr_ne1(v.d)); }
+MARAY_DEV mr_m mr_stepsin_bounded_m(const mr_d &v) { return mr_m(mr_stepsin_bounded_m(v.a), mr_stepsin_bounded_m(v.b), mr_stepsin_bounded_m(v.c), mr_stepsin_bounded_m(v.d)); }
+MARAY_DEV mr_d mr_neg(const mr_d &v) { return MR_EACH1(mr_neg, v); }
+MARAY_DEV mr_d mr_abs(const mr_d &v) { return MR_EACH1(mr_abs, v); }
+MARAY_DEV mr_d mr_recip(const mr_d &v) { return MR_EACH1(mr_recip, v); }
+MARAY_DEV mr_d mr_sqrt(const mr_d &v) { return MR_EACH1(mr_sqrt, v); }
+MARAY_DEV mr_d mr_sin(const mr_d &v) { return MR_EACH1(mr_sin, v); }
+MARAY_DEV mr_d mr_sin_bounded(const mr_d &v) { return MR_EACH1(mr_sin_bounded, v); }
+MARAY_DEV mr_d mr_exp(const mr_d &v) { return MR_EACH1(mr_exp, v); }
+MARAY_DEV mr_d mr_ln(const mr_d &v) { return MR_EACH1(mr_ln, v); }
+MARAY_DEV mr_d mr_stepsin(const mr_d &v) { return MR_EACH1(mr_stepsin, v); }
+MARAY_DEV mr_d mr_stepsin_fast(const mr_d &v, float *defer)
+{
+    return mr_d(mr_stepsin_fast(v.a, defer), mr_stepsin_fast(v.b, defer), mr_stepsin_fast(v.c, defer), mr_stepsin_fast(v.d, defer));
+}
+MARAY_DEV mr_d mr_max(const mr_d &x, const mr_d &y) { return mr_d(mr_max(x.a, y.a), mr_max(x.b, y.b), mr_max(x.c, y.c), mr_max(x.d, y.d)); }
+MARAY_DEV mr_d mr_min(const mr_d &x, const mr_d &y) { return mr_d(mr_min(x.a, y.a), mr_min(x.b, y.b), mr_min(x.c, y.c), mr_min(x.d, y.d)); }
+MARAY_DEV mr_d mr_app(const MarayTex *tex, unsigned id, const mr_d &x, const mr_d &y)
+{
+    return mr_d(mr_app(tex, id, x.a, y.a), mr_app(tex, id, x.b, y.b), mr_app(tex, id, x.c, y.c), mr_app(tex, id, x.d, y.d));
+}
+#endif

@@ -27,6 +27,7 @@
 
 #include "backend.hpp"
 #include "device_math.h"
+#include "host_pipe.hpp"
 #include "maray_hip.h"
 
 namespace maray {
@@ -604,9 +605,11 @@ struct TapeBackend final : Backend {
     uint32_t *d_row_job_off = nullptr, *d_row_job_len = nullptr, *d_job_id = nullptr, *d_queue = nullptr;
     uint32_t n_row_jobs = 0;
     uint32_t xrows_slot = 0, xguards_slot = 0;
-    unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;
-    double *d_rgb64 = nullptr; size_t rgb64_cap = 0;
-    hipStream_t own_stream = nullptr;
+    unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;      // time_rows without a caller's buffer
+    HostPipe pipe;                      // streams + staging of the host-raster entry points
+    hipStream_t own_stream = nullptr;   // = pipe's compute stream
+    hipStream_t last_stream = nullptr; bool have_last = false;      // the stream of the last launch (see launch())
+    hipEvent_t handover = nullptr;
     // launch geometry of the pixel kernel
     uint32_t n_lds_slots = 0, lds_bytes = 0, blocks_per_cu = 1;
     uint32_t row_lds_slots = 0, row_lds_bytes = 0;
@@ -616,11 +619,11 @@ struct TapeBackend final : Backend {
         (void)hipSetDevice(device);
         (void)hipFree(d_row_ops); (void)hipFree(d_pix_ops); (void)hipFree(d_consts); (void)hipFree(d_tex);
         for (auto p : d_tex_rgb) (void)hipFree(p);
-        (void)hipFree(d_yvals); (void)hipFree(d_spill); (void)hipFree(d_rgb8); (void)hipFree(d_rgb64);
+        (void)hipFree(d_yvals); (void)hipFree(d_spill); (void)hipFree(d_rgb8);
         (void)hipFree(d_guard_ops); (void)hipFree(d_job_off); (void)hipFree(d_job_len); (void)hipFree(d_gbits);
         (void)hipFree(d_xtape_bits); (void)hipFree(d_xtape_rows); (void)hipFree(d_xrows); (void)hipFree(d_xguards);
         (void)hipFree(d_row_job_off); (void)hipFree(d_row_job_len); (void)hipFree(d_job_id); (void)hipFree(d_queue);
-        if (own_stream) (void)hipStreamDestroy(own_stream);
+        if (handover) (void)hipEventDestroy(handover);
     }
 
     void init(int dev, const maray_program &prog, const maray_texture *tex, uint32_t n_tex, bool lds_variant) {
@@ -631,7 +634,9 @@ struct TapeBackend final : Backend {
             throw Error{MARAY_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only"};
         P = prog;
         P.consts = nullptr; P.row_ops = nullptr; P.pix_ops = nullptr;   // host pointers are borrowed for this call only
-        HIP_TRY(hipStreamCreate(&own_stream));
+        pipe.init(dev);
+        own_stream = pipe.compute_stream();
+        HIP_TRY(hipEventCreateWithFlags(&handover, hipEventDisableTiming));
         auto up = [&](const void *src, size_t bytes, void **dst) {
             HIP_TRY(hipMalloc(dst, bytes ? bytes : 8));
             if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
@@ -775,6 +780,13 @@ struct TapeBackend final : Backend {
                 const unsigned *tile_list = nullptr, const double *ext_yvals = nullptr) {
         const uint32_t rows = rb.n_rows, y0 = rb.y0;
         if (!rows || !w) return;
+        // scratch tables and work queues belong to the context: launches are ordered by their stream, and a launch on
+        // another stream than the last one first waits for what that one holds (one event, only at the hand-over)
+        if (have_last && st != last_stream) {
+            HIP_TRY(hipEventRecord(handover, last_stream));
+            HIP_TRY(hipStreamWaitEvent(st, handover, 0));
+        }
+        last_stream = st; have_last = true;
         HIP_TRY(hipMemsetAsync(d_queue, 0, 8, st));              // both kernels' work queues start at 0
         (void)hipGetLastError();        // the launches below are checked with hipGetLastError(): drop what an earlier, unrelated call left
         if (!ext_yvals) ensure(d_yvals, yvals_cap, (size_t)rows * std::max<uint32_t>(P.n_yvals, 1));
@@ -869,15 +881,11 @@ struct TapeBackend final : Backend {
         launch(w, rb, (unsigned char *)d8, (double *)d64, (hipStream_t)stream, false, flags, yvals);
     }
 
-    void render_host(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint8_t *rgb8, double *rgb64) override {
+    void render_host_tiles(uint32_t w, uint32_t, const std::vector<RowTile> &tiles, uint32_t row0, uint8_t *rgb8, double *rgb64,
+                           const std::function<void(uint32_t, uint32_t)> &done) override {
         HIP_TRY(hipSetDevice(device));
-        const size_t n = (size_t)(y1 - y0) * w * 3;
-        if (rgb8) ensure(d_rgb8, rgb8_cap, n);
-        if (rgb64) ensure(d_rgb64, rgb64_cap, n);
-        launch(w, RowBlocks::range(y0, y1), rgb8 ? d_rgb8 : nullptr, rgb64 ? d_rgb64 : nullptr, own_stream, true);
-        if (rgb8) HIP_TRY(hipMemcpyAsync(rgb8, d_rgb8, n, hipMemcpyDeviceToHost, own_stream));
-        if (rgb64) HIP_TRY(hipMemcpyAsync(rgb64, d_rgb64, n * 8, hipMemcpyDeviceToHost, own_stream));
-        HIP_TRY(hipStreamSynchronize(own_stream));
+        pipe.run(w, tiles, row0, rgb8, rgb64,
+                 [&](const RowBlocks &rb, unsigned char *d8, double *d64, hipStream_t st) { launch(w, rb, d8, d64, st, true); }, done);
     }
 
     float time_rows(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, void *d8, void *d64, int reps) override {

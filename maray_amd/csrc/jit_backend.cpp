@@ -19,21 +19,32 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "backend.hpp"
+#include "host_pipe.hpp"
 #include "maray_hip.h"
 
 extern "C" const char maray_embedded_device_math_h[];
 extern "C" const char maray_embedded_libm_h[];
 extern "C" const char maray_embedded_libm_tables_h[];
+
+static const char JIT_OPTIONS[] = "--offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -std=c++17";     // of jit_compile; part of the cache key
 
 namespace maray {
 
@@ -107,6 +118,8 @@ struct Emitter {
     bool assume_guards_zero = false;             // PIXEL: emit the variant for a tile none of whose guard bits is set
     bool out_guard_bits = false;                 // ROW-section OUT of a guard (index >= guard_first): OR its bit into `gacc`
     bool ktab = false;
+    uint32_t min_region = 0;                    // PIXEL: wave-level SKIP ops over fewer ops than this are ignored
+    std::string td = "double", tm = "mr_mask";  // types of a value / a boolean in the generated text ("mr_d" / "mr_m": four pixels per lane)
     std::vector<double> ktab_vals;
     std::unordered_map<uint64_t, uint32_t> ktab_block;
     explicit Emitter(const maray_program &p) : P(p) {}
@@ -160,7 +173,7 @@ struct Emitter {
             if (v->b == "MR_NONE") return v->d = v->kind == BOOL ? "0.0" : "(-0.0)";
             if (v->b == "MR_ALL") return v->d = v->kind == BOOL ? "1.0" : "(-1.0)";
             snprintf(name, sizeof name, "%s%u_%c", hint, i, which ? 'b' : 'a');
-            out += "    const double ";
+            out += "    const " + td + " ";
             out += name;
             out += v->kind == BOOL ? " = mr_pos(" + v->b + ");\n" : " = mr_neg01(" + v->b + ");\n";
             v->d = name;
@@ -182,6 +195,7 @@ struct Emitter {
                 const uint32_t gref = MARAY_INS_A(ins);
                 const bool row_guard = pixel && MARAY_REF_KIND(gref) == MARAY_K_YVAL;
                 if (row_guard && ignore_row_guards) continue;      // legal: an evaluator may ignore any SKIP op
+                if (!row_guard && pixel && aux < min_region) continue;     // a wave-level region too short to pay for its test and branch
                 // the region's variable is a lane mask when its last op yields one: the guard tells for a wave-level
                 // region (a boolean guards a boolean AND / OR), the dry run for a row-level one (its guard is a y value)
                 const bool as_bool = row_guard ? (end < bool_hint.size() && bool_hint[end]) : va->kind == BOOL;
@@ -206,13 +220,13 @@ struct Emitter {
                     const std::string k = std::to_string(MARAY_REF_INDEX(gref));
                     cond = nz ? "!(yw[2 * " + k + " + 1] == 0x3ff00000u && yw[2 * " + k + "] == 0u)"
                               : "((yw[2 * " + k + " + 1] << 1) | yw[2 * " + k + "]) != 0u";
-                } else if (as_bool) cond = nz ? "~" + va->b + " != MR_NONE" : va->b + " != MR_NONE";      // a scalar compare
-                else cond = "mr_ballot(" + dbl(va, "m", i, 0) + (nz ? " != 1.0) != MR_NONE" : " != 0.0) != MR_NONE");
+                } else if (as_bool) cond = nz ? "mr_any(~" + va->b + ")" : "mr_any(" + va->b + ")";      // a scalar compare
+                else cond = (nz ? "mr_any(mr_ne1(" : "mr_any(mr_ne0(") + dbl(va, "m", i, 0) + "))";
                 // several regions may end at one op (a row-level guard around a wave-level one): one variable
                 bool typed_bool = as_bool;
                 bool declared = false;
                 for (const Open &o : open) if (o.end == end) { declared = true; typed_bool = o.as_bool; }
-                if (!declared) out += typed_bool ? "    mr_mask b" + std::string(name) + ";\n" : "    double " + std::string(name) + ";\n";
+                if (!declared) out += typed_bool ? "    " + tm + " b" + std::string(name) + ";\n" : "    " + td + " " + std::string(name) + ";\n";
                 // regions are entered rarely (chess: 2-20 %): mark them unlikely so that the block placement keeps the
                 // skip path as the fall-through and moves the region bodies out of line (taken jumps stall on instruction fetch)
                 out += "    if (__builtin_expect(" + cond + ", 0)) {\n";
@@ -259,9 +273,9 @@ struct Emitter {
                 if (va->kind == BOOL) { r.kind = NEGBOOL; r.b = va->b; }
                 else e = "mr_neg(" + dbl(va, "m", i, 0) + ")";
                 break;
-            case MARAY_OP_STEP: be = "mr_ballot(" + dbl(va, "m", i, 0) + " >= 0.0)"; break;
+            case MARAY_OP_STEP: be = "mr_ge0(" + dbl(va, "m", i, 0) + ")"; break;
             case MARAY_OP_STEPSIN:
-                if (aux & MARAY_AUX_SIN_BOUNDED) be = "mr_ballot(mr_stepsin_bounded_b(" + dbl(va, "m", i, 0) + "))";
+                if (aux & MARAY_AUX_SIN_BOUNDED) be = "mr_stepsin_bounded_m(" + dbl(va, "m", i, 0) + ")";
                 else e = pixel ? "mr_stepsin_fast(" + dbl(va, "m", i, 0) + ", &mr_defer)" : "mr_stepsin(" + dbl(va, "m", i, 0) + ")";
                 break;
             case MARAY_OP_ADD:
@@ -305,7 +319,7 @@ struct Emitter {
                     r.kind = BOOL; r.b = "b" + self;
                 } else if (o.as_bool) {
                     // guard was boolean but the result is not typed so: keep the double form
-                    out += "    b" + self + " = mr_ballot((" + e + ") != 0.0);\n    } else b" + self + (o.nz ? " = MR_ALL;\n" : " = MR_NONE;\n");
+                    out += "    b" + self + " = mr_ne0(" + e + ");\n    } else b" + self + (o.nz ? " = MR_ALL;\n" : " = MR_NONE;\n");
                     r.kind = BOOL; r.b = "b" + self;
                 } else {
                     const std::string ee = !e.empty() ? e : (be == "MR_NONE" ? "0.0" : be == "MR_ALL" ? "1.0" : "mr_pos(" + be + ")");
@@ -323,10 +337,10 @@ struct Emitter {
             } else if (!be.empty() && be[0] != '(' && be[0] != '~' && be.compare(0, 3, "mr_") != 0) {
                 r.kind = BOOL; r.b = be;             // folded to one of its operands: an alias, no new variable
             } else if (!be.empty()) {
-                out += "    const mr_mask b" + self + " = " + be + ";\n";
+                out += "    const " + tm + " b" + self + " = " + be + ";\n";
                 r.kind = BOOL; r.b = "b" + self;
             } else if (!e.empty()) {
-                out += "    const double " + self + " = " + e + ";\n";
+                out += "    const " + td + " " + self + " = " + e + ";\n";
                 r.kind = DBL; r.d = self;
             }
             vals[i] = r;
@@ -491,6 +505,179 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
     return s;
 }
 
+// Pixels per lane of the specialised PIXEL kernel: 4 (default; a wavefront owns a 256-pixel tile) or 1 (the first
+// layout: a wavefront owns 64 pixels, a block stages its tiles' guard words in LDS; MARAY_JIT_PX=1, kept as an ablation).
+uint32_t jit_px()
+{
+    const char *e_ = getenv("MARAY_JIT_PX");
+    return (e_ && e_[0] == '1') ? 1u : 4u;
+}
+
+// Source of the PIXEL kernel, four pixels per lane.  A wavefront owns `tiles` consecutive 256-pixel tiles of one row
+// (blockIdx.y; the four wavefronts of a block take four neighbouring strips and share nothing but the instruction
+// cache: no LDS staging, no barrier).  Per tile: the tile's guard words arrive by scalar loads, one scalar test picks
+// the variant (no guard bit set: every guarded region is the literal 0), every value is four f64 per lane and every
+// boolean four lane masks (device_math.h, MR_VEC4), so the scalar unit's share of a tile -- bit tests, region branches,
+// constant and y-value loads -- is paid once per 256 pixels.  RGB8: a lane's four pixels are 12 contiguous bytes, one
+// global_store_dwordx3.  When f64 planes are wanted too, element e of lane l is pixel x0 + 64 e + l instead, so that
+// each of the four element stores is the coalesced pattern of the one-pixel layout.
+static std::string jit_source_px4(const maray_program &P, int min_waves_arg)
+{
+    Emitter E(P);
+    E.td = "mr_d"; E.tm = "mr_m";
+    if (const char *e_ = getenv("MARAY_JIT_MIN_REGION")) E.min_region = (uint32_t)atoi(e_);
+    std::string &s = E.out;
+    const char *env_waves = getenv("MARAY_JIT_WAVES");
+    const int min_waves = env_waves ? atoi(env_waves) : min_waves_arg;
+    const uint32_t n_ynum = numeric_yvals(P);
+    const uint32_t n_gwords = jit_guard_words(P);
+    E.ignore_row_guards = n_gwords == 0;
+    if (n_gwords) { E.guard_first = n_ynum; E.guard_words = n_gwords; }
+    const bool defer = may_defer_tiles(P);
+    const std::string nw = std::to_string(n_gwords);
+    s += "// generated by libmaray_hip (jit_backend.cpp) from a v" + std::to_string(P.version) + " tape: PIXEL section, " +
+         std::to_string(P.n_pix_ops) + " ops, four pixels per lane\n"
+         "#define MR_VEC4 1\n"
+         "__shared__ unsigned mr_slow[4];           // per wavefront: some Sin of the tile at hand needs the slow path\n"
+         "__device__ inline double mr_defer_sin(double) { ((volatile unsigned *)mr_slow)[threadIdx.x >> 6] = 1u; return 0.0; }\n"
+         "#define MR_SIN_HUGE(x) mr_defer_sin(x)   // plain Sin ops: flag the tile from the (rare) branch\n"
+         "#include \"device_math.h\"\n"
+         "typedef const __attribute__((address_space(4))) double *mr_kptr;\n"
+         "typedef const __attribute__((address_space(4))) unsigned long long *mr_gptr;\n"
+         "struct __attribute__((aligned(4))) mr_u3 { unsigned a, b, c; };\n/*MR_KTAB*/\n";
+    s += "extern \"C\" __global__ void __launch_bounds__(256" + (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string()) +
+         ") maray_jit_pixels(unsigned char *__restrict__ rgb8, double *__restrict__ rgb64,\n"
+         "                                                                    const double *__restrict__ yvals, const MarayTex *__restrict__ tex,\n"
+         "                                                                    unsigned *__restrict__ tile_list, unsigned tile_base,\n"
+         "                                                                    const unsigned long long *__restrict__ gbits, unsigned n_tx,\n"
+         "                                                                    unsigned w, unsigned y0, unsigned n_yvals, unsigned tiles,\n"
+         "                                                                    unsigned blk_rows, unsigned blk_stride, unsigned row_base, unsigned yrows,\n"
+         "                                                                    const unsigned *__restrict__ row_order)\n{\n"
+         "    const unsigned mr_wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), mr_lane = threadIdx.x & 63u;\n"
+         "    const unsigned tile0 = (blockIdx.x * 4u + mr_wv) * tiles;               // this wavefront's strip of the row\n"
+         "    if (tile0 >= n_tx) return;\n"
+         "    const unsigned r = row_order ? row_order[blockIdx.y] : blockIdx.y;     // row of this launch (dearest groups of rows first); row_base + r = row of the whole call\n"
+         "    unsigned long long mr_ybase = (unsigned long long)(yvals + (size_t)r * n_yvals);\n"
+         "    const double Y = (double)(y0 + ((row_base + r) / blk_rows) * blk_stride + (row_base + r) % blk_rows);     // -> image row (RowBlocks)\n"
+         "    (void)Y; (void)tex; (void)gbits; (void)yrows; (void)tile_list; (void)tile_base;\n";
+    if (n_gwords)
+        s += "    unsigned long long mr_gbase = (unsigned long long)(gbits + ((size_t)((row_base + r) / yrows) * n_tx + tile0) * " + nw + "u);\n";
+    s += "    const bool mr_wide = rgb64 == nullptr;                                   // element e of lane l: pixel x0 + 4 l + e, else x0 + 64 e + l\n"
+         "    const unsigned mr_xl = mr_wide ? 4u * mr_lane : mr_lane, mr_xs = mr_wide ? 1u : 64u;\n"
+         "    const unsigned mr_src = (mr_lane * 4u) / 3u, mr_shift = ((mr_lane * 4u) % 3u) * 8u;   // one-pixel RGB8 packing (f64 planes wanted too)\n"
+         "    for (unsigned t = 0; t < tiles; t++) {\n"
+         "    const unsigned x0 = (tile0 + t) * 256u;\n"
+         "    if (x0 >= w) break;\n"
+         "    asm volatile(\"\" : \"+s\"(mr_ybase));          // y values, constants, guard words: scalar loads where they are used, not hoisted out of the loop\n"
+         "    mr_kptr yv = (mr_kptr)mr_ybase;\n"
+         "    const __attribute__((address_space(4))) unsigned *yw = (const __attribute__((address_space(4))) unsigned *)yv;\n"
+         "    (void)yv; (void)yw;\n"
+         "/*MR_KBASE*/";
+    if (n_gwords) {
+        s += "    asm volatile(\"\" : \"+s\"(mr_gbase));\n"
+             "    const mr_gptr mr_gk = (mr_gptr)mr_gbase + t * " + nw + "u;\n";
+        if (n_gwords <= 12)
+            for (uint32_t j = 0; j < n_gwords; j++)
+                s += "    const mr_mask gq" + std::to_string(j) + " = mr_gk[" + std::to_string(j) + "u];\n";
+        else
+            s += "    const mr_gptr mr_gqt = mr_gk;        // this tile's guard words, read where they are tested\n";
+    }
+    if (defer) s += "    ((volatile unsigned *)mr_slow)[mr_wv] = 0u;\n";
+    s += "    const unsigned xa = x0 + mr_xl;                                        // this lane's first pixel\n"
+         "    const mr_d X((double)xa, (double)(xa + mr_xs), (double)(xa + 2u * mr_xs), (double)(xa + 3u * mr_xs));\n"
+         "    mr_d o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"
+         "    float mr_defer = 0.0f;                     // fused Step(Sin) ops count their undecided cases in here\n"
+         "    (void)X; (void)mr_defer;\n";
+    if (!E.ignore_row_guards) {         // dry run: which ops yield lane masks
+        Emitter D(P);
+        D.ignore_row_guards = true;
+        D.min_region = E.min_region;
+        D.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+        E.bool_hint = D.is_bool_op;
+    }
+    {
+        const char *e_ = getenv("MARAY_JIT_KTAB");
+        E.ktab = !(e_ && e_[0] == '0');
+    }
+    if (n_gwords) {
+        if (n_gwords <= 12) {
+            std::string any = "gq0";
+            for (uint32_t j = 1; j < n_gwords; j++) any += " | gq" + std::to_string(j);
+            s += "    if ((" + any + ") == 0ull) {\n";
+        } else {
+            s += "    mr_mask mr_any_g = 0ull;\n"
+                 "    for (unsigned i = 0; i < " + nw + "u; i++) mr_any_g |= mr_gqt[i];\n"
+                 "    if (mr_any_g == 0ull) {\n";
+        }
+        E.assume_guards_zero = true;
+        E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+        E.assume_guards_zero = false;
+        s += "    } else {\n";
+        E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+        s += "    }\n";
+    } else
+        E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+    {
+        std::string tab;
+        if (!E.ktab_vals.empty()) {
+            tab = "__constant__ double mr_kc_tab[" + std::to_string(E.ktab_vals.size()) + "] = {";
+            for (size_t j = 0; j < E.ktab_vals.size(); j++) { tab += (j % 6 ? " " : "\n    "); tab += lit(E.ktab_vals[j]); tab += ","; }
+            tab += "\n};\n";
+        }
+        s.replace(s.find("/*MR_KTAB*/"), 11, tab);
+        s.replace(s.find("/*MR_KBASE*/"), 12, E.ktab_vals.empty() ? "    asm volatile(\"\" ::: \"memory\");\n" :
+                  "    unsigned long long mr_kbase = (unsigned long long)mr_kc_tab;\n"
+                  "    asm volatile(\"\" : \"+s\"(mr_kbase) :: \"memory\");\n"
+                  "    const mr_kptr mr_kc = (mr_kptr)mr_kbase;\n");
+    }
+    if (defer)
+        s += "    if (mr_ballot(mr_defer != 0.0f) != 0ull || ((volatile unsigned *)mr_slow)[mr_wv] != 0u) {      // wave-uniform\n"
+             "        if (mr_lane == 0u) tile_list[1u + atomicAdd(&tile_list[0], 1u)] = tile_base + r * n_tx + tile0 + t;\n"
+             "    }\n";
+    // outputs
+    s += "    const unsigned p0 = mr_cast_u8(o0.a) | (mr_cast_u8(o1.a) << 8) | (mr_cast_u8(o2.a) << 16);\n"
+         "    const unsigned p1 = mr_cast_u8(o0.b) | (mr_cast_u8(o1.b) << 8) | (mr_cast_u8(o2.b) << 16);\n"
+         "    const unsigned p2 = mr_cast_u8(o0.c) | (mr_cast_u8(o1.c) << 8) | (mr_cast_u8(o2.c) << 16);\n"
+         "    const unsigned p3 = mr_cast_u8(o0.d) | (mr_cast_u8(o1.d) << 8) | (mr_cast_u8(o2.d) << 16);\n"
+         "    const size_t row_px = (size_t)r * w;\n"
+         "    if (mr_wide) {\n"
+         "        if (rgb8) {\n"
+         "            unsigned char *q = rgb8 + (row_px + xa) * 3;                      // this lane's 12 bytes\n"
+         "            if (x0 + 256u <= w && ((size_t)(rgb8 + (row_px + x0) * 3) & 3u) == 0u) {      // wave-uniform\n"
+         "                mr_u3 d;\n"
+         "                d.a = p0 | (p1 << 24); d.b = (p1 >> 8) | (p2 << 16); d.c = (p2 >> 16) | (p3 << 8);\n"
+         "                *(mr_u3 *)q = d;\n"
+         "            } else {\n"
+         "                const unsigned pk[4] = {p0, p1, p2, p3};\n"
+         "                for (unsigned e = 0; e < 4u; e++)\n"
+         "                    if (xa + e < w) { q[3 * e] = (unsigned char)pk[e]; q[3 * e + 1] = (unsigned char)(pk[e] >> 8); q[3 * e + 2] = (unsigned char)(pk[e] >> 16); }\n"
+         "            }\n"
+         "        }\n"
+         "    } else {\n"
+         "        const unsigned pk[4] = {p0, p1, p2, p3};\n"
+         "        const double c0[4] = {o0.a, o0.b, o0.c, o0.d}, c1[4] = {o1.a, o1.b, o1.c, o1.d}, c2[4] = {o2.a, o2.b, o2.c, o2.d};\n"
+         "        _Pragma(\"unroll\") for (unsigned e = 0; e < 4u; e++) {\n"
+         "            const unsigned xw = x0 + 64u * e, x = xw + mr_lane;          // first pixel of this element's 64-pixel run; this lane's pixel\n"
+         "            if (x < w) { const size_t p = (row_px + x) * 3; rgb64[p] = c0[e]; rgb64[p + 1] = c1[e]; rgb64[p + 2] = c2[e]; }\n"
+         "            if (rgb8) {\n"
+         "                unsigned char *wave_out = rgb8 + (row_px + xw) * 3;\n"
+         "                if (xw + 64u <= w && ((size_t)wave_out & 3u) == 0u) {                // wave-uniform\n"
+         "                    const unsigned pa = (unsigned)__builtin_amdgcn_ds_bpermute((int)(mr_src * 4u), (int)pk[e]);\n"
+         "                    const unsigned pb = (unsigned)__builtin_amdgcn_ds_bpermute((int)(mr_src * 4u + 4u), (int)pk[e]);\n"
+         "                    const unsigned dw = (unsigned)((((unsigned long long)pb << 24) | pa) >> mr_shift);\n"
+         "                    if (mr_lane < 48u) ((unsigned *)wave_out)[mr_lane] = dw;\n"
+         "                } else if (x < w) {\n"
+         "                    unsigned char *q = rgb8 + (row_px + x) * 3;\n"
+         "                    q[0] = (unsigned char)pk[e]; q[1] = (unsigned char)(pk[e] >> 8); q[2] = (unsigned char)(pk[e] >> 16);\n"
+         "                }\n"
+         "            }\n"
+         "        }\n"
+         "    }\n"
+         "    }\n"
+         "}\n";
+    return s;
+}
+
 // Source of the PIXEL kernel: one work-item per pixel, block = 256 consecutive
 // pixels of one row (a "tile"), blockIdx.y = row of this launch.  A Sin whose
 // argument is huge (|x| >= 105414350), inf or NaN does not call the slow
@@ -500,6 +687,8 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
 std::string jit_source(const maray_program &P, int min_waves_arg)
 {
     validate_program(P);
+    if (min_waves_arg == 0) min_waves_arg = jit_px() == 4 ? 4 : 8;
+    if (jit_px() == 4) return jit_source_px4(P, min_waves_arg);
     Emitter E(P);
     std::string &s = E.out;
     s += "// generated by libmaray_hip (jit_backend.cpp) from a v" + std::to_string(P.version) + " tape: PIXEL section, " +
@@ -702,7 +891,8 @@ void jit_compile(const std::string &src, std::vector<char> &code, std::string &l
     const char *headers[] = {maray_embedded_device_math_h, maray_embedded_libm_h, maray_embedded_libm_tables_h};
     const char *names[] = {"device_math.h", "maray_libm.h", "maray_libm_tables.h"};
     RTC_TRY(hiprtcCreateProgram(&prog, src.c_str(), "maray_jit.hip", 3, headers, names));
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17"};
+    const char *olevel = getenv("MARAY_JIT_OPT");          // measurement knob: "-O1" builds faster
+    const char *opts[] = {"--offload-arch=gfx950", (olevel && olevel[0] == '-') ? olevel : "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17"};
     hiprtcResult rc = hiprtcCompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
     size_t ln = 0;
     hiprtcGetProgramLogSize(prog, &ln);
@@ -719,6 +909,170 @@ void jit_compile(const std::string &src, std::vector<char> &code, std::string &l
     hiprtcDestroyProgram(&prog);
 }
 
+// ---- code objects: built once per (program, toolchain), kept in the process and on disk ------------------------
+//
+// The reference's JIT compiles its three modules again on every thread of every render (src/render.rs:158-165).
+// Here a program's two code objects (PIXEL and ROW kernels) are a pure function of the generated sources, the
+// compiler options and the hiprtc that builds them: they are built once, shared by every context of the process
+// (one per device of a multi-GPU render: the second device loads what the first one built), and stored under
+// MARAY_CACHE_DIR (default $XDG_CACHE_HOME/maray_amd or ~/.cache/maray_amd; "off" disables) for the next process.
+namespace {
+
+uint64_t fnv1a(const void *data, size_t n, uint64_t h)
+{
+    const unsigned char *p = (const unsigned char *)data;
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+
+// an unsigned field of the kernel's metadata note (msgpack: the value follows its key)
+long code_meta_uint(const std::vector<char> &co, const char *key)
+{
+    const size_t kn = strlen(key);
+    const auto it = std::search(co.begin(), co.end(), key, key + kn);
+    if (it == co.end() || (size_t)(co.end() - it) < kn + 5) return -1;
+    const unsigned char *v = (const unsigned char *)&*it + kn;
+    if (v[0] <= 0x7f) return v[0];
+    if (v[0] == 0xcc) return v[1];
+    if (v[0] == 0xcd) return ((long)v[1] << 8) | v[2];
+    if (v[0] == 0xce) return ((long)v[1] << 24) | ((long)v[2] << 16) | ((long)v[3] << 8) | v[4];
+    return -1;
+}
+
+std::string cache_dir()
+{
+    const char *e = getenv("MARAY_CACHE_DIR");
+    if (e) {
+        if (!e[0] || !strcmp(e, "off") || !strcmp(e, "0")) return "";
+        return e;
+    }
+    if (const char *x = getenv("XDG_CACHE_HOME")) if (x[0]) return std::string(x) + "/maray_amd";
+    if (const char *h = getenv("HOME")) if (h[0]) return std::string(h) + "/.cache/maray_amd";
+    return "";
+}
+
+void mkdirs(const std::string &d)
+{
+    for (size_t i = 1; i <= d.size(); i++)
+        if (i == d.size() || d[i] == '/') (void)mkdir(d.substr(0, i).c_str(), 0777);
+}
+
+const uint32_t CACHE_MAGIC = 0x6f63726du;    // "mrco"
+
+bool cache_read(const std::string &path, JitCode &c)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    uint32_t hdr[6];
+    bool ok = fread(hdr, 4, 6, f) == 6 && hdr[0] == CACHE_MAGIC && hdr[4] < (1u << 30) && hdr[5] < (1u << 30);
+    if (ok) {
+        c.n_row_chunks = hdr[1]; c.n_gjobs = hdr[2]; c.waves = (int)hdr[3];
+        c.pix.resize(hdr[4]); c.rows.resize(hdr[5]);
+        ok = fread(c.pix.data(), 1, c.pix.size(), f) == c.pix.size() && fread(c.rows.data(), 1, c.rows.size(), f) == c.rows.size();
+        uint64_t sum = 0;
+        ok = ok && fread(&sum, 8, 1, f) == 1 && sum == fnv1a(c.rows.data(), c.rows.size(), fnv1a(c.pix.data(), c.pix.size(), 0xcbf29ce484222325ull));
+    }
+    fclose(f);
+    return ok;
+}
+
+void cache_write(const std::string &dir, const std::string &path, const JitCode &c)
+{
+    mkdirs(dir);
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return;                                       // a read-only or missing cache directory is not an error
+    const uint32_t hdr[6] = {CACHE_MAGIC, c.n_row_chunks, c.n_gjobs, (uint32_t)c.waves, (uint32_t)c.pix.size(), (uint32_t)c.rows.size()};
+    const uint64_t sum = fnv1a(c.rows.data(), c.rows.size(), fnv1a(c.pix.data(), c.pix.size(), 0xcbf29ce484222325ull));
+    const bool ok = fwrite(hdr, 4, 6, f) == 6 && fwrite(c.pix.data(), 1, c.pix.size(), f) == c.pix.size() &&
+                    fwrite(c.rows.data(), 1, c.rows.size(), f) == c.rows.size() && fwrite(&sum, 8, 1, f) == 1;
+    if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());      // rename: readers never see half a file
+}
+
+std::mutex g_code_mutex;
+std::map<std::string, std::shared_future<std::shared_ptr<const JitCode>>> g_code;
+
+struct CodeKey { std::string hex, src_pix, src_rows; uint32_t n_row_chunks = 1, n_gjobs = 0; };
+
+CodeKey code_key(const maray_program &prog)
+{
+    CodeKey k;
+    k.src_pix = jit_source(prog);
+    if (prog.n_row_ops) k.src_rows = jit_source_rows(prog, &k.n_row_chunks, &k.n_gjobs);
+    int major = 0, minor = 0;
+    (void)hiprtcVersion(&major, &minor);          // a process that imported PyTorch first compiles with PyTorch's own hiprtc
+    const std::string salt = std::string(maray_version()) + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) +
+                             "|" + JIT_OPTIONS + "|" + (getenv("MARAY_JIT_OPT") ? getenv("MARAY_JIT_OPT") : "");
+    uint64_t h1 = fnv1a(salt.data(), salt.size(), 0xcbf29ce484222325ull), h2 = fnv1a(salt.data(), salt.size(), 0x84222325cbf29ce4ull);
+    for (const std::string *t : {&k.src_pix, &k.src_rows}) { h1 = fnv1a(t->data(), t->size() + 1, h1); h2 = fnv1a(t->data(), t->size() + 1, h2); }
+    for (const char *hd : {maray_embedded_device_math_h, maray_embedded_libm_h, maray_embedded_libm_tables_h}) { h1 = fnv1a(hd, strlen(hd), h1); h2 = fnv1a(hd, strlen(hd), h2); }
+    char buf[40];
+    snprintf(buf, sizeof buf, "%016llx%016llx", (unsigned long long)h1, (unsigned long long)h2);
+    k.hex = buf;
+    return k;
+}
+
+std::shared_ptr<const JitCode> build_code(const maray_program &prog, const CodeKey &k)
+{
+    auto c = std::make_shared<JitCode>();
+    const std::string dir = cache_dir(), path = dir.empty() ? "" : dir + "/" + k.hex + ".mrco";
+    if (!path.empty() && cache_read(path, *c)) { c->from_disk = true; return c; }
+    std::string log;
+    // Occupancy: the highest of 8 / 6 / 4 waves per SIMD (<= 64 / 80 / 128 VGPRs) whose build needs no scratch:
+    // spilled VGPRs are HBM traffic.  MARAY_JIT_WAVES=<n> forces a build for n waves.
+    // Four pixels per lane: values are four times as wide and a build takes four times as long; the hint is then a
+    // ceiling the compiler is free to stay under (it reports what it used), 4 waves = 128 VGPRs, then 2 = 256.
+    const bool px4 = jit_px() == 4;
+    const int ladder[] = {px4 ? 4 : 8, px4 ? 2 : 6, px4 ? 1 : 4};
+    for (int i = 0; i < 3; i++) {
+        jit_compile(i == 0 ? k.src_pix : jit_source(prog, ladder[i]), c->pix, log);
+        c->waves = ladder[i];
+        if (code_meta_uint(c->pix, ".private_segment_fixed_size") <= 0 || getenv("MARAY_JIT_WAVES")) break;
+    }
+    if (prog.n_row_ops) jit_compile(k.src_rows, c->rows, log);
+    c->n_row_chunks = k.n_row_chunks; c->n_gjobs = k.n_gjobs;
+    if (!path.empty()) cache_write(dir, path, *c);
+    return c;
+}
+
+}   // namespace
+
+std::string jit_code_key(const maray_program &prog) { return code_key(prog).hex; }
+
+bool jit_code_is_cached(const maray_program &prog)
+{
+    const CodeKey k = code_key(prog);
+    {
+        std::lock_guard<std::mutex> lk(g_code_mutex);
+        if (g_code.count(k.hex)) return true;
+    }
+    const std::string dir = cache_dir();
+    return !dir.empty() && access((dir + "/" + k.hex + ".mrco").c_str(), R_OK) == 0;
+}
+
+std::shared_ptr<const JitCode> jit_code_for(const maray_program &prog)
+{
+    const CodeKey k = code_key(prog);
+    std::promise<std::shared_ptr<const JitCode>> mine;
+    std::shared_future<std::shared_ptr<const JitCode>> fut;
+    bool build = false;
+    {
+        std::lock_guard<std::mutex> lk(g_code_mutex);
+        auto it = g_code.find(k.hex);
+        if (it != g_code.end()) fut = it->second;
+        else { fut = mine.get_future().share(); g_code.emplace(k.hex, fut); build = true; }
+    }
+    if (build) {
+        try { mine.set_value(build_code(prog, k)); }
+        catch (...) {
+            mine.set_exception(std::current_exception());
+            std::lock_guard<std::mutex> lk(g_code_mutex);
+            g_code.erase(k.hex);                       // a failed build is not remembered (the waiters still see its error)
+        }
+    }
+    return fut.get();         // the contexts of a multi-GPU render: the first builds, the others wait here
+}
+
 namespace {
 
 #define HIP_TRY(expr)                                                                              \
@@ -733,6 +1087,7 @@ struct DevTex { const unsigned char *rgb; unsigned w, h; };
 struct JitBackend final : Backend {
     int device = 0;
     maray_program P{};
+    std::shared_ptr<const JitCode> code;
     hipModule_t mod = nullptr, mod_rows = nullptr;
     hipFunction_t f_rows = nullptr, f_pix = nullptr, f_order = nullptr;
     unsigned *d_order = nullptr; size_t order_cap = 0;
@@ -742,12 +1097,15 @@ struct JitBackend final : Backend {
     DevTex *d_tex = nullptr;
     std::vector<unsigned char *> d_tex_rgb;
     double *d_yvals = nullptr; size_t yvals_cap = 0;
-    unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;
-    double *d_rgb64 = nullptr; size_t rgb64_cap = 0;
-    hipStream_t own_stream = nullptr;
+    unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;      // time_rows without a caller's buffer
+    HostPipe pipe;                      // streams + staging of the host-raster entry points
+    hipStream_t own_stream = nullptr;   // = pipe's compute stream
     uint32_t n_row_chunks = 1, n_gwords = 0, n_gjobs = 0, guard_rows = 1;
+    uint32_t px = 4;                    // pixels per lane of the PIXEL kernel this context was built with
     unsigned long long *d_gbits = nullptr; size_t gbits_cap = 0;
     bool has_sin = false;               // some Sin argument is not proven bounded: tiles may be deferred to `slow`
+    hipStream_t last_stream = nullptr; bool have_last = false;      // the stream of the last launch (see launch())
+    hipEvent_t handover = nullptr;
 
     ~JitBackend() override {
         (void)hipSetDevice(device);
@@ -758,8 +1116,8 @@ struct JitBackend final : Backend {
         (void)hipFree(d_tex);
         for (auto p : d_tex_rgb) (void)hipFree(p);
         (void)hipFree(d_gbits); (void)hipFree(d_order);
-        (void)hipFree(d_yvals); (void)hipFree(d_rgb8); (void)hipFree(d_rgb64);
-        if (own_stream) (void)hipStreamDestroy(own_stream);
+        (void)hipFree(d_yvals); (void)hipFree(d_rgb8);
+        if (handover) (void)hipEventDestroy(handover);
     }
 
     void init(int dev, const maray_program &prog, const maray_texture *tex, uint32_t n_tex) {
@@ -770,34 +1128,25 @@ struct JitBackend final : Backend {
         if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
             throw Error{MARAY_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only"};
         has_sin = may_defer_tiles(prog);
-        std::vector<char> code, code_rows;
-        std::string log;
-        // Occupancy: the highest of 8 / 6 / 4 waves per SIMD (<= 64 / 80 / 128 VGPRs) whose build needs no scratch:
-        // spilled VGPRs are HBM traffic.  (chess needs 36-40 VGPRs since its row regions are private: the first build
-        // is taken.  MARAY_JIT_WAVES=<n> forces a build for n waves.)
-        const int ladder[] = {8, 6, 4};
-        for (int k = 0; k < 3; k++) {
-            if (mod) { (void)hipModuleUnload(mod); mod = nullptr; }
-            jit_compile(jit_source(prog, ladder[k]), code, log);
-            HIP_TRY(hipModuleLoadData(&mod, code.data()));
-            HIP_TRY(hipModuleGetFunction(&f_pix, mod, "maray_jit_pixels"));
-            int scratch = 0;
-            HIP_TRY(hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f_pix));
-            if (scratch == 0 || getenv("MARAY_JIT_WAVES")) break;
-        }
-        if (prog.n_row_ops) jit_compile(jit_source_rows(prog, &n_row_chunks, &n_gjobs), code_rows, log);
+        px = jit_px();
+        code = jit_code_for(prog);                       // built by the first context of the process, or read from the cache
+        HIP_TRY(hipModuleLoadData(&mod, code->pix.data()));
+        HIP_TRY(hipModuleGetFunction(&f_pix, mod, "maray_jit_pixels"));
+        n_row_chunks = code->n_row_chunks; n_gjobs = code->n_gjobs;
         slow = make_tape_backend(dev, prog, tex, n_tex, false);
         P = prog;
         P.consts = nullptr; P.row_ops = nullptr; P.pix_ops = nullptr;
         if (prog.n_row_ops) {
-            HIP_TRY(hipModuleLoadData(&mod_rows, code_rows.data()));
+            HIP_TRY(hipModuleLoadData(&mod_rows, code->rows.data()));
             HIP_TRY(hipModuleGetFunction(&f_rows, mod_rows, "maray_jit_rows"));
             n_gwords = jit_guard_words(prog);
             if (n_gwords && !(getenv("MARAY_JIT_NO_ORDER") && getenv("MARAY_JIT_NO_ORDER")[0] == '1')) HIP_TRY(hipModuleGetFunction(&f_order, mod_rows, "maray_jit_order"));
             guard_rows = jit_guard_rows(prog);
 
         }
-        HIP_TRY(hipStreamCreate(&own_stream));
+        pipe.init(dev);
+        own_stream = pipe.compute_stream();
+        HIP_TRY(hipEventCreateWithFlags(&handover, hipEventDisableTiming));
         std::vector<DevTex> descs(n_tex ? n_tex : 1);
         for (uint32_t i = 0; i < n_tex; i++) {
             unsigned char *d = nullptr;
@@ -824,6 +1173,14 @@ struct JitBackend final : Backend {
         const uint32_t rows_total = rb.n_rows, y0 = rb.y0;
         unsigned blk_rows = rb.block_rows, blk_stride = rb.block_stride;
         if (!rows_total || !w) return;
+        // The scratch tables (y values, guard bits, row order, work list) belong to the context, not to a launch: launches
+        // are ordered by the stream they are issued on.  When a launch arrives on another stream than the last one, that
+        // stream is made to wait for everything the previous one holds (one event, only at the hand-over).
+        if (have_last && st != last_stream) {
+            HIP_TRY(hipEventRecord(handover, last_stream));
+            HIP_TRY(hipStreamWaitEvent(st, handover, 0));
+        }
+        last_stream = st; have_last = true;
         // rows per guard evaluation: a group must not straddle two row blocks (its image rows have to be consecutive)
         unsigned yrows = (guard_rows > 1 && (blk_rows >= rows_total || blk_rows % guard_rows == 0)) ? guard_rows : 1u;
         const uint32_t n_groups = (rows_total + yrows - 1) / yrows;
@@ -848,27 +1205,39 @@ struct JitBackend final : Backend {
             void *args[] = {&d_yvals, &d_gbits, &d_tex, &yy0, &rr, &n_yvals, &ww, &n_tx_, &blk_rows, &blk_stride, &yrows};
             HIP_TRY(hipModuleLaunchKernel(f_rows, (unsigned)((items + bs - 1) / bs), n_row_chunks + n_gjobs, 1, bs, 1, 1, 0, st, args, nullptr));
         }
-        // launch order of the PIXEL kernel (maray_jit_order): once per geometry, from the guard bits the ROW kernel just wrote
+        // launch order of the PIXEL kernel (maray_jit_order): once per geometry, from the guard bits the ROW kernel just wrote;
+        // a cached order is used by every launch of that geometry, with or without a ROW pass (time_rows)
         const unsigned *row_order = nullptr;
-        if (f_order && rows_pass && n_gwords && rows_total <= 65535 && n_groups <= 4096 && n_groups > 1) {
+        if (f_order && n_gwords && rows_total <= 65535 && n_groups <= 4096 && n_groups > 1) {
             const uint64_t key[3] = {((uint64_t)w << 32) | rows_total, ((uint64_t)y0 << 32) | blk_rows, ((uint64_t)blk_stride << 32) | yrows};
-            if (key[0] != order_key[0] || key[1] != order_key[1] || key[2] != order_key[2]) {
+            const bool cached = key[0] == order_key[0] && key[1] == order_key[1] && key[2] == order_key[2];
+            if (!cached && rows_pass) {
+                order_key[0] = order_key[1] = order_key[2] = 0;     // no geometry owns d_order until the kernel below is enqueued
                 ensure(d_order, order_cap, (size_t)rows_total);
                 unsigned rr = rows_total, n_tx_ = (w + 255) / 256;
                 void *oargs[] = {&d_gbits, &d_order, &rr, &n_tx_, &yrows};
                 HIP_TRY(hipModuleLaunchKernel(f_order, 1, 1, 1, 256, 1, 1, n_groups * 4, st, oargs, nullptr));
                 order_key[0] = key[0]; order_key[1] = key[1]; order_key[2] = key[2];
             }
-            row_order = d_order;
+            if (key[0] == order_key[0] && key[1] == order_key[1] && key[2] == order_key[2]) row_order = d_order;
         }
         const unsigned n_tx = (w + 255) / 256;
         const uint64_t n_tiles = (uint64_t)n_tx * rows_total;
         // tiles per block: amortise the per-block prologue, but rows cost what they show (sky: nothing, board: 5x the
         // average) and blocks are the unit of load balance (chess @4096^2, tiles = 2 / 4 / 8 / 16: 68 / 59 / 52 / 58 us;
         // walking the rows in a scattered order to mix cheap and dear ones costs more in cache locality than it balances)
-        unsigned tiles = has_sin ? 1u : (unsigned)std::min<uint64_t>(std::min<uint64_t>(8, n_tx), std::max<uint64_t>(1, n_tiles / 4096));
-        if (const char *e_ = getenv("MARAY_JIT_TILES")) if (!has_sin && atoi(e_) > 0) tiles = (unsigned)std::min(n_gwords > 12 ? 8 : 16, atoi(e_));      // tuning knob (the kernel stages guard words for <= 16 / 8 tiles)
-        const unsigned gx = (n_tx + tiles - 1) / tiles;
+        unsigned tiles, gx;
+        if (px == 4) {
+            // four pixels per lane: a wavefront owns `tiles` consecutive tiles of a row, a block four such strips
+            tiles = 2;
+            if (const char *e_ = getenv("MARAY_JIT_TILES")) if (atoi(e_) > 0) tiles = (unsigned)std::min(64, atoi(e_));      // tuning knob
+            tiles = std::min(tiles, n_tx);
+            gx = (n_tx + 4 * tiles - 1) / (4 * tiles);
+        } else {
+            tiles = has_sin ? 1u : (unsigned)std::min<uint64_t>(std::min<uint64_t>(8, n_tx), std::max<uint64_t>(1, n_tiles / 4096));
+            if (const char *e_ = getenv("MARAY_JIT_TILES")) if (!has_sin && atoi(e_) > 0) tiles = (unsigned)std::min(n_gwords > 12 ? 8 : 16, atoi(e_));      // tuning knob (the kernel stages guard words for <= 16 / 8 tiles)
+            gx = (n_tx + tiles - 1) / tiles;
+        }
         if (n_tiles > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
         ensure(d_flags, flags_cap, (size_t)n_tiles + 1);                    // work list {count, tile, ...} of deferred tiles
         if (has_sin) HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(unsigned), st));
@@ -878,7 +1247,7 @@ struct JitBackend final : Backend {
             double *p64 = d64 ? d64 + (size_t)r0 * w * 3 : nullptr;
             const double *yv = d_yvals + (size_t)r0 * n_yvals;
             unsigned *fl = d_flags;
-            unsigned ww = w, yy0 = y0, tile_base = r0 * gx, row_base = r0;
+            unsigned ww = w, yy0 = y0, tile_base = r0 * (px == 4 ? n_tx : gx), row_base = r0;
             const unsigned long long *gb = d_gbits;              // indexed by the row of the whole call
             unsigned ntx = n_tx;
             void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles, &blk_rows, &blk_stride, &row_base, &yrows, &row_order};
@@ -892,15 +1261,11 @@ struct JitBackend final : Backend {
         launch(w, rb, (unsigned char *)d8, (double *)d64, (hipStream_t)stream, true);
     }
 
-    void render_host(uint32_t w, uint32_t, uint32_t y0, uint32_t y1, uint8_t *rgb8, double *rgb64) override {
+    void render_host_tiles(uint32_t w, uint32_t, const std::vector<RowTile> &tiles, uint32_t row0, uint8_t *rgb8, double *rgb64,
+                           const std::function<void(uint32_t, uint32_t)> &done) override {
         HIP_TRY(hipSetDevice(device));
-        const size_t n = (size_t)(y1 - y0) * w * 3;
-        if (rgb8) ensure(d_rgb8, rgb8_cap, n);
-        if (rgb64) ensure(d_rgb64, rgb64_cap, n);
-        launch(w, RowBlocks::range(y0, y1), rgb8 ? d_rgb8 : nullptr, rgb64 ? d_rgb64 : nullptr, own_stream, true);
-        if (rgb8) HIP_TRY(hipMemcpyAsync(rgb8, d_rgb8, n, hipMemcpyDeviceToHost, own_stream));
-        if (rgb64) HIP_TRY(hipMemcpyAsync(rgb64, d_rgb64, n * 8, hipMemcpyDeviceToHost, own_stream));
-        HIP_TRY(hipStreamSynchronize(own_stream));
+        pipe.run(w, tiles, row0, rgb8, rgb64,
+                 [&](const RowBlocks &rb, unsigned char *d8, double *d64, hipStream_t st) { launch(w, rb, d8, d64, st, true); }, done);
     }
 
     float time_rows(uint32_t w, uint32_t, uint32_t y0, uint32_t y1, void *d8, void *d64, int reps) override {

@@ -9,8 +9,13 @@
 // non-interlaced gray / RGB / palette / gray+alpha / RGBA at 8 or 16 bits
 // (and 1/2/4-bit gray or palette), converted like `to_rgb8` (alpha dropped,
 // 16-bit -> high byte... see below).
+//
+// Both entry points take sizes from outside (the caller; a texture file's IHDR):
+// every product of sizes is checked in 64 bits against MARAY_PNG_MAX_BYTES before
+// anything is allocated or indexed, and no exception crosses the C boundary.
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -38,6 +43,20 @@ void chunk(std::vector<uint8_t> &out, const char *type, const uint8_t *data, siz
 
 uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
+// Raster sizes this library will read or write: 2^20 pixels a side (the evaluators' own limit,
+// MARAY_DOMAIN_MAX) and 16 GiB of filtered scanlines.  A crafted IHDR beyond that is rejected, not allocated.
+const uint64_t MARAY_PNG_MAX_BYTES = 1ull << 34;
+
+template <typename F>
+int png_guard(F f)
+{
+    try { return f(); }
+    catch (const Error &e) { set_last_error(e.msg); return e.code; }
+    catch (const std::bad_alloc &) { set_last_error("out of memory"); return MARAY_E_INTERNAL; }
+    catch (const std::exception &e) { set_last_error(e.what()); return MARAY_E_INTERNAL; }
+    catch (...) { set_last_error("unknown error"); return MARAY_E_INTERNAL; }
+}
+
 int paeth(int a, int b, int c)
 {
     int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
@@ -49,7 +68,11 @@ int paeth(int a, int b, int c)
 
 extern "C" int maray_png_write(const char *path, const uint8_t *rgb8, uint32_t w, uint32_t h)
 {
+    return png_guard([&]() -> int {
     if (!path || (!rgb8 && (uint64_t)w * h)) { set_last_error("null argument"); return MARAY_E_ARG; }
+    if (w > MARAY_DOMAIN_MAX || h > MARAY_DOMAIN_MAX || ((uint64_t)w * 3 + 1) * h > MARAY_PNG_MAX_BYTES) {
+        set_last_error("image too large for the PNG writer"); return MARAY_E_LIMIT;
+    }
     std::vector<uint8_t> raw;
     raw.reserve(((size_t)w * 3 + 1) * h);
     for (uint32_t y = 0; y < h; y++) {
@@ -64,7 +87,10 @@ extern "C" int maray_png_write(const char *path, const uint8_t *rgb8, uint32_t w
     put_be32(ihdr, w); put_be32(ihdr, h);
     ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);   // 8-bit, truecolour
     chunk(out, "IHDR", ihdr.data(), ihdr.size());
-    chunk(out, "IDAT", z.data(), zn);
+    for (size_t off = 0; off < zn || off == 0; off += (size_t)1 << 30) {          // a chunk's length field holds 31 bits
+        chunk(out, "IDAT", z.data() + off, std::min<size_t>((size_t)1 << 30, zn - off));
+        if (zn == 0) break;
+    }
     chunk(out, "IEND", nullptr, 0);
     FILE *f = fopen(path, "wb");
     if (!f) { set_last_error(std::string("cannot create ") + path); return MARAY_E_IO; }
@@ -72,12 +98,14 @@ extern "C" int maray_png_write(const char *path, const uint8_t *rgb8, uint32_t w
     fclose(f);
     if (n != out.size()) { set_last_error("short write"); return MARAY_E_IO; }
     return MARAY_OK;
+    });
 }
 
 extern "C" int maray_png_read(const char *path, uint8_t **rgb8_out, uint32_t *w_out, uint32_t *h_out)
 {
     if (!path || !rgb8_out || !w_out || !h_out) { set_last_error("null argument"); return MARAY_E_ARG; }
     *rgb8_out = nullptr;
+    return png_guard([&]() -> int {
     FILE *f = fopen(path, "rb");
     if (!f) { set_last_error(std::string("cannot open ") + path); return MARAY_E_IO; }
     std::vector<uint8_t> b;
@@ -117,8 +145,16 @@ extern "C" int maray_png_read(const char *path, uint8_t **rgb8_out, uint32_t *w_
     if (!(depth == 8 || depth == 16 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) {
         set_last_error("bad PNG bit depth"); return MARAY_E_DECODE;
     }
-    const size_t bpp_bits = (size_t)channels * depth;
-    const size_t stride = ((size_t)w * bpp_bits + 7) / 8;
+    const size_t bpp_bits = (size_t)channels * depth;                 // <= 64
+    // sizes straight from the file: bound them before any product is formed (w, h <= 2^20 keeps every product below 2^47)
+    if (w > MARAY_DOMAIN_MAX || h > MARAY_DOMAIN_MAX) { set_last_error("PNG larger than 1048576 pixels a side"); return MARAY_E_LIMIT; }
+    const uint64_t stride64 = ((uint64_t)w * bpp_bits + 7) / 8;
+    if ((stride64 + 1) * h > MARAY_PNG_MAX_BYTES || (uint64_t)w * h * 3 > MARAY_PNG_MAX_BYTES) {
+        set_last_error("PNG raster exceeds the reader's size limit"); return MARAY_E_LIMIT;
+    }
+    // a zlib stream expands at most 1032:1: an IHDR that promises more than the IDAT bytes can hold is rejected unallocated
+    if ((stride64 + 1) * h > ((uint64_t)idat.size() + 1) * 1040) { set_last_error("PNG inflate failed (IDAT too short for its IHDR)"); return MARAY_E_DECODE; }
+    const size_t stride = (size_t)stride64;
     const size_t bpp = (bpp_bits + 7) / 8;
     std::vector<uint8_t> raw((stride + 1) * h);
     uLongf rn = (uLongf)raw.size();
@@ -169,4 +205,5 @@ extern "C" int maray_png_read(const char *path, uint8_t **rgb8_out, uint32_t *w_
     }
     *rgb8_out = out; *w_out = w; *h_out = h;
     return MARAY_OK;
+    });
 }

@@ -37,9 +37,9 @@ def test_chess_uses_the_pure_bounded_step_sin(chess_bytes):
     assert L.maray_jit_source(C.byref(tape.program), C.byref(src)) == 0
     text = C.string_at(src).decode()
     L.maray_free(src)
-    assert text.count('mr_stepsin_bounded_b(') == 256 and 'mr_stepsin_fast(' not in text
-    assert text.count('const mr_mask ') > 2500       # half of chess is boolean algebra on lane masks (SGPR pairs)
-    assert text.count('mr_mask bv') > 3600 and ' bool ' not in text.split('maray_jit_pixels')[1]
+    assert text.count('mr_stepsin_bounded_m(') == 256 and 'mr_stepsin_fast(' not in text
+    assert text.count('const mr_m ') > 2500       # half of chess is boolean algebra on lane masks (SGPR pairs), four per value
+    assert text.count('mr_m bv') > 3600 and ' bool bv' not in text and ' bool v' not in text
 
 
 def test_row_section_is_cut_into_chunks(chess_bytes):

@@ -19,7 +19,7 @@ def test_reader_and_lowering_under_asan_ubsan(tmp_path):
     a = src.index('void validate_program(const maray_program &p)')
     b = src.index('}   // namespace maray', a)
     with open(shim, 'w') as f:
-        f.write('#include <string>\n#include <vector>\n#include "expr.hpp"\n#include "lower.hpp"\n#include "maray_hip.h"\nnamespace maray {\n'
+        f.write('#include <string>\n#include <vector>\n#include "expr.hpp"\n#include "lower.hpp"\n#include "maray_hip.h"\nnamespace maray {\nuint32_t numeric_yvals(const maray_program &P);\n'
                 + src[a:b] + '}\n')
     subprocess.check_call(['g++', '-std=c++17', '-O1', '-g', '-fsanitize=address,undefined', '-fno-sanitize-recover=all',
                            '-ffp-contract=off', '-I' + csrc, '-I' + os.path.join(ROOT, 'include'),

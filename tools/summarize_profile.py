@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     tag, kernel = sys.argv[1], sys.argv[2]
-    rnd = sys.argv[sys.argv.index('--round') + 1] if '--round' in sys.argv else 'r1'
+    rnd = sys.argv[sys.argv.index('--round') + 1] if '--round' in sys.argv else 'r2'
     src = os.path.join(ROOT, 'gpurun_out', 'prof_' + tag)
     dst = os.path.join(ROOT, 'profiles', '%s_%s_chess4096_' % (rnd, tag))
     stats = glob.glob(src + '/trace/*/*_kernel_stats.csv')[0]
@@ -62,7 +62,10 @@ def main():
         d['salu_insts_per_cycle_per_cu'] = avg['SQ_INSTS_SALU'] / 256 / cyc
     if 'SQ_WAVE_CYCLES' in avg:
         d['wave_cycles_per_wave (SQ_WAVE_CYCLES*4/SQ_WAVES)'] = avg['SQ_WAVE_CYCLES'] * 4 / waves
-    out = {'command': 'rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py %s --steps 3 --warmup 1 '
+    import subprocess
+    commit = subprocess.run(['git', '-C', ROOT, 'rev-parse', 'HEAD'], capture_output=True, text=True).stdout.strip() or None
+    out = {'commit': commit, 'code_key': bench['config'].get('code_key'),
+           'command': 'rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py %s --steps 3 --warmup 1 '
                       '(tools/profile_bench.sh: one run per counter group)' % ' '.join(sys.argv[3:] if '--round' not in sys.argv else []),
            'kernel': kernel, 'workload': bench['config']['workload'] + ', one launch = %d pixels' % px,
            'per_launch_average': avg, 'resources': res, 'derived': d}
