@@ -323,8 +323,9 @@ int maray_hip_ctx_create(int device, const maray_program *prog, const maray_text
             // interpreter 4.4 us per megapixel and executed op, of which guards skip ~95 % when the program has any.
             const char *force = getenv("MARAY_AUTO");          // "jit" / "tape": override (measurements)
             bool want_jit = prog->n_pix_ops <= 25000;
-            if (want_jit && opts && opts->hint_mpixels && !jit_code_is_cached(*prog)) {
-                const double build_s = 0.5 + 4.0e-4 * prog->n_pix_ops + 2.4e-4 * prog->n_row_ops;
+            if (want_jit && opts && opts->hint_mpixels) {
+                // cached code objects still cost a context ~0.2 s (key = the generated sources, two module loads)
+                const double build_s = jit_code_is_cached(*prog) ? 0.2 : 0.5 + 4.0e-4 * prog->n_pix_ops + 2.4e-4 * prog->n_row_ops;
                 const bool guarded = prog->n_yvals > numeric_yvals(*prog);
                 const double interp_s = (double)opts->hint_mpixels * prog->n_pix_ops * 4.4e-6 * (guarded ? 0.05 : 1.0);
                 want_jit = interp_s > build_s;

@@ -63,6 +63,10 @@ MARAY_DEV mr_mask mr_ne0(double a) { return mr_ballot(a != 0.0); }
 MARAY_DEV mr_mask mr_ne1(double a) { return mr_ballot(a != 1.0); }
 MARAY_DEV mr_mask mr_stepsin_bounded_m(double a) { return mr_ballot(maray_libm_step_sin_bounded(a) != 0.0); }
 MARAY_DEV bool mr_any(mr_mask m) { return m != MR_NONE; }
+// a y value known to be +0.0 or 1.0 (the same on every lane) as a lane mask: one scalar load and compare on its high word
+// (the high word is 0 or 0x3ff00000: bit 20 spread over a mask by integer arithmetic.  Written as a select, the back end may
+// keep the boolean in a VGPR across blocks, and the mask then reaches v_cndmask's scalar operand from a vector register.)
+MARAY_DEV mr_mask mr_ym(const __attribute__((address_space(4))) unsigned *yw, unsigned k) { return (mr_mask)0 - (mr_mask)((yw[2u * k + 1u] >> 20) & 1u); }
 
 // Rust `f64 as u8` (src/render.rs:92-94): saturating, NaN -> 0, truncation.
 MARAY_DEV unsigned mr_cast_u8(double v)

@@ -108,12 +108,12 @@ extern "C" int maray_gen_to_image(const maray_scene *s, const maray_texture *tex
     if (n_dev_avail > 0 && n_dev > (uint32_t)n_dev_avail)
         return fail_with(MARAY_E_NO_DEVICE, "asked for " + std::to_string(n_dev) + " devices, " + std::to_string(n_dev_avail) + " visible");
     if (n_dev > (h + 7) / 8) n_dev = (h + 7) / 8;
-    // Row tiles: ~8 MiB of raster each (the DMA engine's rate; the first copy starts early), but at least four per
+    // Row tiles: ~16 MiB of raster each (the DMA engine's rate; the first copy starts early), but at least four per
     // device, dealt round-robin: the cost of a row depends on what it shows (the kernels skip work tile by tile), so
     // contiguous bands would leave the device with the busiest band behind.  Multiples of 8 rows (guard groups).
     uint32_t tile_rows = opts && opts->tile_rows ? opts->tile_rows : 0;
     if (!tile_rows) {
-        const uint64_t by_bytes = std::max<uint64_t>(8, (((uint64_t)8 << 20) / ((uint64_t)w * 3)) / 8 * 8);
+        const uint64_t by_bytes = std::max<uint64_t>(8, (((uint64_t)16 << 20) / ((uint64_t)w * 3)) / 8 * 8);
         const uint64_t by_share = std::max<uint64_t>(8, ((uint64_t)h / (4ull * n_dev) + 7) / 8 * 8);
         tile_rows = (uint32_t)std::min(by_bytes, n_dev > 1 ? by_share : by_bytes);
     }

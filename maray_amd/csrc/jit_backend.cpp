@@ -119,6 +119,13 @@ struct Emitter {
     bool out_guard_bits = false;                 // ROW-section OUT of a guard (index >= guard_first): OR its bit into `gacc`
     bool ktab = false;
     uint32_t min_region = 0;                    // PIXEL: wave-level SKIP ops over fewer ops than this are ignored
+    // y values that are booleans (exactly +0.0 or 1.0 on every row: a Step of y-only arguments and what AND / OR / NOT make
+    // of such): the PIXEL section reads them as lane masks (all lanes or none) from a scalar compare, so that min / max /
+    // mul with them stay mask algebra.  Left as numbers they turn every shape they clip -- and then the whole OR tree of
+    // shapes above -- into f64 code: three v_max, a v_cndmask and a v_cmp where one s_or_b64 does.
+    std::vector<uint8_t> ybool;                 // PIXEL in: per y value; ROW out (dry run): what each OUT wrote
+    std::vector<uint8_t> out_is_bool;
+    int stage_first = -1;                       // ROW: >= 0: OUT k goes to LDS, ys[(k - stage_first) * 65 + lane] (jit_source_rows)
     std::string td = "double", tm = "mr_mask";  // types of a value / a boolean in the generated text ("mr_d" / "mr_m": four pixels per lane)
     std::vector<double> ktab_vals;
     std::unordered_map<uint64_t, uint32_t> ktab_block;
@@ -153,7 +160,10 @@ struct Emitter {
                 else if (bits == 0) { t.kind = BOOL; t.b = "MR_NONE"; }
                 return &t;
             }
-            case MARAY_K_YVAL: t.d = yv_name + "[" + std::to_string(idx) + "]"; return &t;
+            case MARAY_K_YVAL:
+                t.d = yv_name + "[" + std::to_string(idx) + "]";
+                if (idx < ybool.size() && ybool[idx]) { t.kind = BOOL; t.b = "mr_ym(yw, " + std::to_string(idx) + "u)"; }
+                return &t;
             default:
                 if (idx == MARAY_SPEC_ACC) return &vals[acc];
                 static const char *const spec_name[] = {"X", "Y", "", "XMAX", "XMIN", "YMAX", "YMIN"};
@@ -235,12 +245,14 @@ struct Emitter {
                 continue;
             }
             if (op == MARAY_OP_OUT) {
+                if (!pixel) { if (out_is_bool.size() <= aux) out_is_bool.resize(aux + 1, 0); out_is_bool[aux] = va->kind == BOOL; }
                 const std::string a = dbl(va, "m", i, 0);
                 if (!pixel && out_guard_bits && aux >= guard_first)
                     out += "    gacc |= (" + a + " != 0.0) ? (1ull << " + std::to_string((aux - guard_first) % 8) + ") : 0ull;\n";
                 else
                     out += pixel ? "    o" + std::to_string(aux) + " = " + a + ";\n"
-                                 : "    yout[" + std::to_string(aux) + "] = " + a + ";\n";
+                           : stage_first >= 0 ? "    ys[" + std::to_string((aux - (uint32_t)stage_first) * 65) + "u + mr_lane] = " + a + ";\n"
+                                              : "    yout[" + std::to_string(aux) + "] = " + a + ";\n";
                 continue;
             }
             Val *vb = (op >= MARAY_OP_ADD && op <= MARAY_OP_APP && !forced[i]) ? ref(MARAY_INS_B(ins), 1) : nullptr;
@@ -353,35 +365,62 @@ struct Emitter {
 
 }   // namespace
 
+// Which y values are booleans: a dry run of the emitter over the ROW section (its typing is the one the PIXEL section
+// will rely on).  MARAY_JIT_YBOOL=0: none (ablation).
+std::vector<uint8_t> jit_bool_yvals(const maray_program &P)
+{
+    std::vector<uint8_t> r(P.n_yvals, 0);
+    const char *e_ = getenv("MARAY_JIT_YBOOL");
+    if (!P.n_row_ops || (e_ && e_[0] == '0')) return r;
+    Emitter D(P);
+    D.section(P.row_ops, P.n_row_ops, P.n_row_slots, false, "r");
+    const uint32_t n_ynum = numeric_yvals(P);
+    for (uint32_t k = 0; k < P.n_yvals && k < D.out_is_bool.size() && k < n_ynum; k++) r[k] = D.out_is_bool[k];
+    return r;
+}
+
 // The ROW section split into chunks that different wavefronts evaluate side by side.  One
 // work-item per row is all the parallelism a straight-line ROW kernel has (4096 rows = 64 waves,
 // each walking thousands of dependent f64 ops: ~45 us for chess, an eighth of the frame).  The y
 // values are independent outputs, so the tape is cut by outputs: chunk k keeps the ops its outputs
 // depend on (ops two chunks share are computed in both) and the rest become NOPs.
-std::vector<std::vector<uint64_t>> split_row_tape(const maray_program &P, const RowTapeDeps &d, uint32_t out_limit)
+// Chunk k writes the y values [first[k], first[k] + count[k]): outputs are taken in index order, so that a chunk's
+// values are neighbours in a row of the table and leave the kernel as full cache lines (jit_source_rows).
+struct RowChunks {
+    std::vector<std::vector<uint64_t>> tapes;
+    std::vector<uint32_t> first, count;
+};
+static const uint32_t ROW_CHUNK_MAX_OUTS = 16;      // x 65 x 8 B of LDS per wavefront
+
+RowChunks split_row_tape(const maray_program &P, const RowTapeDeps &d, uint32_t out_limit)
 {
     const uint32_t n = P.n_row_ops;
     std::vector<uint32_t> outs;
     for (uint32_t j : d.outs) if (MARAY_INS_AUX(P.row_ops[j]) < out_limit) outs.push_back(j);
+    std::sort(outs.begin(), outs.end(), [&](uint32_t x, uint32_t y) { return MARAY_INS_AUX(P.row_ops[x]) < MARAY_INS_AUX(P.row_ops[y]); });
     size_t total = 0;
     (void)row_tape_cone(P, d, outs, &total);
-    const uint32_t n_chunks = (uint32_t)std::min<size_t>(16, std::max<size_t>(1, total / 256));
+    size_t per_chunk = 64;
+    if (const char *e_ = getenv("MARAY_JIT_ROW_CHUNK_OPS")) if (atoi(e_) > 0) per_chunk = (size_t)atoi(e_);      // tuning knob
+    const uint32_t n_chunks = (uint32_t)std::min<size_t>(64, std::max<size_t>(std::max<size_t>(1, total / per_chunk), (outs.size() + ROW_CHUNK_MAX_OUTS - 1) / ROW_CHUNK_MAX_OUTS));
     const size_t budget = (total + n_chunks - 1) / n_chunks;
-    std::vector<std::vector<uint64_t>> chunks;
+    RowChunks rc;
     size_t next = 0;
     while (next < outs.size()) {
         std::vector<uint32_t> mine;
         size_t cost = 0;
-        std::vector<uint64_t> tape;
-        while (next < outs.size() && (cost < budget || chunks.size() + 1 == n_chunks)) {
+        while (next < outs.size() && mine.size() < ROW_CHUNK_MAX_OUTS && cost < budget) {
+            // a y value with no OUT of its own between two others would break the chunk's index range: a new chunk starts there
+            if (!mine.empty() && MARAY_INS_AUX(P.row_ops[outs[next]]) != MARAY_INS_AUX(P.row_ops[mine.back()]) + 1) break;
             mine.push_back(outs[next++]);
-            if (chunks.size() + 1 == n_chunks) continue;        // the last chunk takes the rest: one cone at the end
-            tape = row_tape_cone(P, d, mine, &cost);
+            (void)row_tape_cone(P, d, mine, &cost);
         }
-        chunks.push_back(row_tape_cone(P, d, mine, &cost));
+        rc.first.push_back(MARAY_INS_AUX(P.row_ops[mine.front()]));
+        rc.count.push_back((uint32_t)mine.size());
+        rc.tapes.push_back(row_tape_cone(P, d, mine, &cost));
     }
-    if (chunks.empty()) chunks.emplace_back(n, 0);
-    return chunks;
+    if (rc.tapes.empty()) { rc.tapes.emplace_back(n, 0); rc.first.push_back(0); rc.count.push_back(0); }
+    return rc;
 }
 
 // How the specialised kernels use the row guards of a program: as bits, 64 per word, one set per
@@ -422,32 +461,51 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
     if (n_gjobs_out) *n_gjobs_out = n_gjobs;
     // the interpreter (which drains deferred tiles from the same y-value table) does read the guard values
     const uint32_t out_limit = may_defer_tiles(P) ? 0xFFFFFFFFu : n_ynum;
-    const std::vector<std::vector<uint64_t>> chunks = split_row_tape(P, deps, out_limit);
+    const RowChunks rc = split_row_tape(P, deps, out_limit);
+    const std::vector<std::vector<uint64_t>> &chunks = rc.tapes;
     if (n_chunks_out) *n_chunks_out = (uint32_t)chunks.size();
     std::string &s = E.out;
     s += "// generated by libmaray_hip (jit_backend.cpp): ROW section, " + std::to_string(P.n_row_ops) + " ops; y values in " +
          std::to_string(chunks.size()) + " chunks, " + std::to_string(P.n_yvals - n_ynum) + " guards in " + std::to_string(n_gwords) + " words\n";
     s += "#include \"device_math.h\"\n\n";
-    s += "extern \"C\" __global__ void __launch_bounds__(256) maray_jit_rows(double *__restrict__ yvals, unsigned long long *__restrict__ gbits,\n"
+    const char *env_rw = getenv("MARAY_JIT_ROW_WAVES");          // tuning knob: occupancy hint of the ROW kernel
+    s += "extern \"C\" __global__ void __launch_bounds__(256" + (env_rw ? ", " + std::string(env_rw) : std::string()) + ") maray_jit_rows(double *__restrict__ yvals, unsigned long long *__restrict__ gbits,\n"
          "                                                                 const MarayTex *__restrict__ tex,\n"
          "                                                                 unsigned y0, unsigned rows, unsigned n_yvals, unsigned w, unsigned n_tx,\n"
          "                                                                 unsigned blk_rows, unsigned blk_stride, unsigned yrows)\n{\n"
          "    const unsigned long long item = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;\n"
          "    (void)tex; (void)gbits; (void)n_tx;\n"
          "    if (blockIdx.y < " + std::to_string(chunks.size()) + "u) {\n"
-         "    if (item >= rows) return;\n"
+         + std::string(getenv("MARAY_JIT_ROW_PART") && getenv("MARAY_JIT_ROW_PART")[0] == '2' ? "    return;      // measurement: guard jobs only (wrong pixels!)\n" : "") +
+         "    // y values: a work-item per row.  A lane's values go to LDS ([value][row], values 65 apart: no bank conflicts either\n"
+         "    // way) and leave as rows of the table, a chunk's values side by side: full cache lines.  Stored from the registers, a\n"
+         "    // wavefront's store touches 64 lines for 8 bytes each -- 1.2 M partial writes per frame, which is what the kernel\n"
+         "    // then waits for (11.8 us; the arithmetic needs 2).\n"
+         "    __shared__ double mr_ys[4 * " + std::to_string(ROW_CHUNK_MAX_OUTS * 65) + "];\n"
+         "    const unsigned mr_lane = threadIdx.x & 63u;\n"
+         "    double *ys = mr_ys + (threadIdx.x >> 6) * " + std::to_string(ROW_CHUNK_MAX_OUTS * 65) + "u;\n"
+         "    const unsigned long long row0 = item - mr_lane;                       // first row of this wavefront\n"
+         "    if (row0 >= rows) return;                                            // whole wavefronts only: every lane helps to store\n"
          "    const unsigned r = (unsigned)item;\n"
          "    const double Y = (double)(y0 + (r / blk_rows) * blk_stride + r % blk_rows), XMIN = 0.0, XMAX = (double)(w - 1u);\n"
          "    const double YMIN = Y, YMAX = Y;\n"
-         "    double *yout = yvals + (size_t)r * n_yvals;\n"
-         "    (void)Y; (void)XMIN; (void)XMAX; (void)YMIN; (void)YMAX; (void)yout; (void)yrows;\n"
+         "    (void)Y; (void)XMIN; (void)XMAX; (void)YMIN; (void)YMAX; (void)yrows;\n"
+         "    unsigned mr_k0 = 0u, mr_kn = 0u;\n"
          "    switch (blockIdx.y) {\n";
     for (size_t k = 0; k < chunks.size(); k++) {
         s += "    case " + std::to_string(k) + ": {\n";
+        E.stage_first = (int)rc.first[k];
         E.section(chunks[k].data(), P.n_row_ops, P.n_row_slots, false, "r");
-        s += "    } break;\n";
+        E.stage_first = -1;
+        s += "    mr_k0 = " + std::to_string(rc.first[k]) + "u; mr_kn = " + std::to_string(rc.count[k]) + "u;\n    } break;\n";
     }
-    s += "    }\n    return;\n    }\n";
+    s += "    }\n"
+         "    __builtin_amdgcn_wave_barrier();                                       // same wavefront: LDS keeps its order\n"
+         "    for (unsigned e = mr_lane; e < 64u * mr_kn; e += 64u) {\n"
+         "        const unsigned row = e / mr_kn, j = e - row * mr_kn;\n"
+         "        if (row0 + row < rows) yvals[(size_t)(row0 + row) * n_yvals + mr_k0 + j] = ys[j * 65u + row];\n"
+         "    }\n"
+         "    return;\n    }\n";
     if (n_gwords) {
         s += "    // guards: (row group, tile), the tiles of a group adjacent\n"
              "    const unsigned n_groups = (rows + yrows - 1u) / yrows;\n"
@@ -513,19 +571,39 @@ uint32_t jit_px()
     return (e_ && e_[0] == '1') ? 1u : 4u;
 }
 
-// Source of the PIXEL kernel, four pixels per lane.  A wavefront owns `tiles` consecutive 256-pixel tiles of one row
-// (blockIdx.y; the four wavefronts of a block take four neighbouring strips and share nothing but the instruction
-// cache: no LDS staging, no barrier).  Per tile: the tile's guard words arrive by scalar loads, one scalar test picks
-// the variant (no guard bit set: every guarded region is the literal 0), every value is four f64 per lane and every
-// boolean four lane masks (device_math.h, MR_VEC4), so the scalar unit's share of a tile -- bit tests, region branches,
-// constant and y-value loads -- is paid once per 256 pixels.  RGB8: a lane's four pixels are 12 contiguous bytes, one
-// global_store_dwordx3.  When f64 planes are wanted too, element e of lane l is pixel x0 + 64 e + l instead, so that
-// each of the four element stores is the coalesced pattern of the one-pixel layout.
-static std::string jit_source_px4(const maray_program &P, int min_waves_arg)
+// Which wavefronts take a tile where shapes may show: one wavefront in four passes of 64 pixels (default), or the block's
+// four side by side, one 64-pixel run each (MARAY_JIT_LAYOUT=coop: every wavefront then walks every tile of the strip,
+// and a strip of sky costs what it did with one pixel per lane: chess 48.5 against 44.4 us per frame, measured).
+bool jit_coop()
+{
+    const char *e_ = getenv("MARAY_JIT_LAYOUT");
+    return e_ && !strcmp(e_, "coop");
+}
+
+// Source of the PIXEL kernel (default layout).  A block of four wavefronts owns `tiles` consecutive 256-pixel tiles
+// of one row (blockIdx.y) and walks them without staging or barriers: every wavefront reads a tile's guard words by
+// scalar loads and one scalar test picks the tile's variant:
+//
+//  * WIDE, four pixels per lane (device_math.h, MR_VEC4: every value four f64, every boolean four lane masks), ONE
+//    wavefront for the whole tile (such tiles are dealt to the block's four wavefronts in turn).  The variant of a tile
+//    none of whose guard bits is set (every guarded region is the literal 0: for chess the background, one multiply),
+//    and the whole section of a small program without guards (config 2: six ops).  The scalar unit's share of a tile
+//    and the store's address arithmetic are paid once per 256 pixels, and a lane's four RGB8 pixels are 12 contiguous
+//    bytes: one global_store_dwordx3, no cross-lane packing.  This is the path that is bound by the store (3 B per
+//    pixel) and little else: a frame of nothing but sky went 22.7 -> 13 us.
+//  * NARROW, one pixel per lane, the four wavefronts side by side on the tile's four 64-pixel runs.  The variant of a
+//    tile where shapes may show.  Regions are entered per 64 pixels, where a wave-level SKIP op still finds all lanes
+//    agreeing; values are single f64 (chess: 20 VGPRs); the four wavefronts walk the same regions at the same time
+//    and share their instruction fetches.  (Carried four wide the same section needs 105 VGPRs, spills a thousand
+//    SGPRs and runs the board 1.5x slower; one wavefront doing the four runs in turn, 1.15x slower: measured.)
+//
+// When f64 planes are wanted too, element e of a wide lane l is pixel x0 + 64 e + l and every 64-pixel run is stored on
+// its own (24 B per lane, the coalesced pattern of the f64 planes).
+static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
 {
     Emitter E(P);
-    E.td = "mr_d"; E.tm = "mr_m";
     if (const char *e_ = getenv("MARAY_JIT_MIN_REGION")) E.min_region = (uint32_t)atoi(e_);
+    E.ybool = jit_bool_yvals(P);
     std::string &s = E.out;
     const char *env_waves = getenv("MARAY_JIT_WAVES");
     const int min_waves = env_waves ? atoi(env_waves) : min_waves_arg;
@@ -535,16 +613,36 @@ static std::string jit_source_px4(const maray_program &P, int min_waves_arg)
     if (n_gwords) { E.guard_first = n_ynum; E.guard_words = n_gwords; }
     const bool defer = may_defer_tiles(P);
     const std::string nw = std::to_string(n_gwords);
+    const bool coop = jit_coop();
+    // a strip's guard words: one vector load per wavefront (lane i holds word i), then v_readlane per tile -- one memory
+    // latency per strip instead of one per tile (MARAY_JIT_GW=sload: scalar loads per tile; measurement knob)
+    const char *env_gw = getenv("MARAY_JIT_GW");
+    const bool gw_vgpr = n_gwords && n_gwords <= 12 && !(env_gw && !strcmp(env_gw, "sload"));
+    // the general section four wide: only a short program whose ops are single instructions (no libm bodies, no gathers)
+    bool heavy = false;
+    for (uint32_t i = 0; i < P.n_pix_ops; i++) {
+        const uint32_t op = MARAY_INS_OP(P.pix_ops[i]);
+        heavy |= op == MARAY_OP_SIN || op == MARAY_OP_EXP || op == MARAY_OP_LN || op == MARAY_OP_STEPSIN || op == MARAY_OP_APP;
+    }
+    bool wide_general = n_gwords == 0 && !heavy && P.n_pix_slots <= 6 && P.n_pix_ops <= 256;
+    if (const char *e_ = getenv("MARAY_JIT_WIDE")) wide_general = e_[0] == '1';            // measurement knob
     s += "// generated by libmaray_hip (jit_backend.cpp) from a v" + std::to_string(P.version) + " tape: PIXEL section, " +
-         std::to_string(P.n_pix_ops) + " ops, four pixels per lane\n"
+         std::to_string(P.n_pix_ops) + " ops; general variant " + (wide_general ? "four pixels per lane, a wavefront per tile" : "one pixel per lane, four wavefronts per tile") + "\n"
          "#define MR_VEC4 1\n"
          "__shared__ unsigned mr_slow[4];           // per wavefront: some Sin of the tile at hand needs the slow path\n"
+         + std::string(coop ? "" : "__shared__ unsigned mr_tp[4 * 256];       // per wavefront: the packed pixels of a tile's four passes\n") +
          "__device__ inline double mr_defer_sin(double) { ((volatile unsigned *)mr_slow)[threadIdx.x >> 6] = 1u; return 0.0; }\n"
          "#define MR_SIN_HUGE(x) mr_defer_sin(x)   // plain Sin ops: flag the tile from the (rare) branch\n"
          "#include \"device_math.h\"\n"
          "typedef const __attribute__((address_space(4))) double *mr_kptr;\n"
          "typedef const __attribute__((address_space(4))) unsigned long long *mr_gptr;\n"
-         "struct __attribute__((aligned(4))) mr_u3 { unsigned a, b, c; };\n/*MR_KTAB*/\n";
+         "struct __attribute__((aligned(4))) mr_u3 { unsigned a, b, c; };\n"
+         "struct __attribute__((aligned(16))) mr_u4 { unsigned a, b, c, d; };\n"
+         "__device__ inline mr_mask mr_lane64(unsigned long long v, unsigned lane)      // lane `lane` (wave-uniform) of a per-lane 64-bit value -> SGPR pair\n"
+         "{\n"
+         "    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, (int)lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), (int)lane);\n"
+         "    return ((mr_mask)hi << 32) | lo;\n"
+         "}\n/*MR_KTAB*/\n";
     s += "extern \"C\" __global__ void __launch_bounds__(256" + (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string()) +
          ") maray_jit_pixels(unsigned char *__restrict__ rgb8, double *__restrict__ rgb64,\n"
          "                                                                    const double *__restrict__ yvals, const MarayTex *__restrict__ tex,\n"
@@ -554,44 +652,52 @@ static std::string jit_source_px4(const maray_program &P, int min_waves_arg)
          "                                                                    unsigned blk_rows, unsigned blk_stride, unsigned row_base, unsigned yrows,\n"
          "                                                                    const unsigned *__restrict__ row_order)\n{\n"
          "    const unsigned mr_wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), mr_lane = threadIdx.x & 63u;\n"
-         "    const unsigned tile0 = (blockIdx.x * 4u + mr_wv) * tiles;               // this wavefront's strip of the row\n"
+         + std::string(coop ? "    const unsigned tile0 = blockIdx.x * tiles;                              // this block's strip of the row\n"
+                            : "    const unsigned tile0 = (blockIdx.x * 4u + mr_wv) * tiles;               // this wavefront's strip of the row\n") +
          "    if (tile0 >= n_tx) return;\n"
          "    const unsigned r = row_order ? row_order[blockIdx.y] : blockIdx.y;     // row of this launch (dearest groups of rows first); row_base + r = row of the whole call\n"
-         "    unsigned long long mr_ybase = (unsigned long long)(yvals + (size_t)r * n_yvals);\n"
+         "    const unsigned long long mr_ybase0 = (unsigned long long)(yvals + (size_t)r * n_yvals);\n"
          "    const double Y = (double)(y0 + ((row_base + r) / blk_rows) * blk_stride + (row_base + r) % blk_rows);     // -> image row (RowBlocks)\n"
          "    (void)Y; (void)tex; (void)gbits; (void)yrows; (void)tile_list; (void)tile_base;\n";
     if (n_gwords)
-        s += "    unsigned long long mr_gbase = (unsigned long long)(gbits + ((size_t)((row_base + r) / yrows) * n_tx + tile0) * " + nw + "u);\n";
-    s += "    const bool mr_wide = rgb64 == nullptr;                                   // element e of lane l: pixel x0 + 4 l + e, else x0 + 64 e + l\n"
+        s += "    const unsigned long long mr_gbase0 = (unsigned long long)(gbits + ((size_t)((row_base + r) / yrows) * n_tx + tile0) * " + nw + "u);\n";
+    if (gw_vgpr)
+        s += "    const unsigned mr_gn = (n_tx - tile0 < tiles ? n_tx - tile0 : tiles) * " + nw + "u;       // <= 64: the host bounds `tiles`\n"
+             "    const unsigned long long mr_gv = mr_lane < mr_gn ? ((const unsigned long long *)mr_gbase0)[mr_lane] : 0ull;\n";
+    s += "    const bool mr_wide = rgb64 == nullptr;                                   // wide variants: element e of lane l is pixel x0 + 4 l + e, else x0 + 64 e + l\n"
          "    const unsigned mr_xl = mr_wide ? 4u * mr_lane : mr_lane, mr_xs = mr_wide ? 1u : 64u;\n"
-         "    const unsigned mr_src = (mr_lane * 4u) / 3u, mr_shift = ((mr_lane * 4u) % 3u) * 8u;   // one-pixel RGB8 packing (f64 planes wanted too)\n"
+         "    const unsigned mr_src = (mr_lane * 4u) / 3u, mr_shift = ((mr_lane * 4u) % 3u) * 8u;   // RGB8 packing of one 64-pixel run\n"
+         "    const size_t row_px = (size_t)r * w;\n"
+         "    unsigned mr_dealt = 0u;                                                  // tiles of this strip that went to ONE wavefront so far\n"
          "    for (unsigned t = 0; t < tiles; t++) {\n"
          "    const unsigned x0 = (tile0 + t) * 256u;\n"
          "    if (x0 >= w) break;\n"
-         "    asm volatile(\"\" : \"+s\"(mr_ybase));          // y values, constants, guard words: scalar loads where they are used, not hoisted out of the loop\n"
-         "    mr_kptr yv = (mr_kptr)mr_ybase;\n"
-         "    const __attribute__((address_space(4))) unsigned *yw = (const __attribute__((address_space(4))) unsigned *)yv;\n"
-         "    (void)yv; (void)yw;\n"
+
+         "    // y values, constants, guard words: scalar loads where they are used, from addresses made opaque in every trip (fresh\n"
+         "    // copies: an asm output carried around the loop counts as divergent once a lane-dependent branch sits in the loop)\n"
          "/*MR_KBASE*/";
     if (n_gwords) {
-        s += "    asm volatile(\"\" : \"+s\"(mr_gbase));\n"
-             "    const mr_gptr mr_gk = (mr_gptr)mr_gbase + t * " + nw + "u;\n";
-        if (n_gwords <= 12)
+        if (!gw_vgpr)
+            s += "    unsigned long long mr_gbase = mr_gbase0;\n"
+                 "    asm volatile(\"\" : \"+s\"(mr_gbase));\n"
+                 "    const mr_gptr mr_gk = (mr_gptr)mr_gbase + t * " + nw + "u;\n";
+        if (gw_vgpr)
             for (uint32_t j = 0; j < n_gwords; j++)
-                s += "    const mr_mask gq" + std::to_string(j) + " = mr_gk[" + std::to_string(j) + "u];\n";
+                s += "    mr_mask gq" + std::to_string(j) + " = mr_lane64(mr_gv, t * " + nw + "u + " + std::to_string(j) + "u);\n";
+        else if (n_gwords <= 12)
+            for (uint32_t j = 0; j < n_gwords; j++)
+                s += "    mr_mask gq" + std::to_string(j) + " = mr_gk[" + std::to_string(j) + "u];\n";
         else
             s += "    const mr_gptr mr_gqt = mr_gk;        // this tile's guard words, read where they are tested\n";
     }
-    if (defer) s += "    ((volatile unsigned *)mr_slow)[mr_wv] = 0u;\n";
-    s += "    const unsigned xa = x0 + mr_xl;                                        // this lane's first pixel\n"
-         "    const mr_d X((double)xa, (double)(xa + mr_xs), (double)(xa + 2u * mr_xs), (double)(xa + 3u * mr_xs));\n"
-         "    mr_d o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"
-         "    float mr_defer = 0.0f;                     // fused Step(Sin) ops count their undecided cases in here\n"
-         "    (void)X; (void)mr_defer;\n";
+    if (defer) s += "    ((volatile unsigned *)mr_slow)[mr_wv] = 0u;\n    bool mr_slow_tile = false;\n";
+    // a tile for one wavefront: the block's four take such tiles in turn
+    const std::string deal = coop ? "    const bool mr_mine = (mr_dealt & 3u) == mr_wv;\n    mr_dealt++;\n    if (mr_mine) {\n" : "    {\n";
     if (!E.ignore_row_guards) {         // dry run: which ops yield lane masks
         Emitter D(P);
         D.ignore_row_guards = true;
         D.min_region = E.min_region;
+        D.ybool = E.ybool;
         D.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
         E.bool_hint = D.is_bool_op;
     }
@@ -599,7 +705,82 @@ static std::string jit_source_px4(const maray_program &P, int min_waves_arg)
         const char *e_ = getenv("MARAY_JIT_KTAB");
         E.ktab = !(e_ && e_[0] == '0');
     }
+    // what opens a pass of either width: the tables made opaque (LICM would hoist every constant and y value out of the
+    // loops and spill them), the pixel coordinates, the outputs
+    const std::string opaque =
+        "    unsigned long long mr_ybase = mr_ybase0;\n"
+        "    asm volatile(\"\" : \"+s\"(mr_ybase));\n"
+        "    mr_kptr yv = (mr_kptr)mr_ybase;\n"
+        "    const __attribute__((address_space(4))) unsigned *yw = (const __attribute__((address_space(4))) unsigned *)yv;\n"
+        "    (void)yv; (void)yw;\n/*MR_KC*/";
+    // the tile's guard words, opaque anew in every pass: left visible, all their bit tests are loop invariants too
+    // (168 booleans for chess, hoisted and spilled to VGPR lanes)
+    std::string gq_pass;
+    if (n_gwords && n_gwords <= 12)
+        for (uint32_t j = 0; j < n_gwords; j++) {
+            const std::string k = std::to_string(j);
+            gq_pass += "    asm volatile(\"\" : \"+s\"(gq" + k + "));\n";
+        }
+    const std::string wide_open =
+        "    {\n" + opaque + gq_pass +
+        "    const unsigned xa = x0 + mr_xl;                                        // this lane's first pixel\n"
+        "    const mr_d X((double)xa, (double)(xa + mr_xs), (double)(xa + 2u * mr_xs), (double)(xa + 3u * mr_xs));\n"
+        "    mr_d o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"
+        "    float mr_defer = 0.0f;                     // fused Step(Sin) ops count their undecided cases in here\n"
+        "    (void)X; (void)mr_defer;\n";
+    const std::string defer_pass = defer ?
+        "    mr_slow_tile |= mr_ballot(mr_defer != 0.0f) != 0ull || ((volatile unsigned *)mr_slow)[mr_wv] != 0u;      // wave-uniform\n" : "";
+    const std::string wide_close = defer_pass +
+        "    const unsigned p0 = mr_cast_u8(o0.a) | (mr_cast_u8(o1.a) << 8) | (mr_cast_u8(o2.a) << 16);\n"
+        "    const unsigned p1 = mr_cast_u8(o0.b) | (mr_cast_u8(o1.b) << 8) | (mr_cast_u8(o2.b) << 16);\n"
+        "    const unsigned p2 = mr_cast_u8(o0.c) | (mr_cast_u8(o1.c) << 8) | (mr_cast_u8(o2.c) << 16);\n"
+        "    const unsigned p3 = mr_cast_u8(o0.d) | (mr_cast_u8(o1.d) << 8) | (mr_cast_u8(o2.d) << 16);\n"
+        "    if (mr_wide) {\n"
+        "        if (rgb8) {\n"
+        "            unsigned char *q = rgb8 + (row_px + xa) * 3;                      // this lane's 12 bytes\n"
+        "            if (x0 + 256u <= w && ((size_t)(rgb8 + (row_px + x0) * 3) & 3u) == 0u) {     // wave-uniform: a whole tile whose bytes start on a dword\n"
+        "                mr_u3 d;\n"
+        "                d.a = p0 | (p1 << 24); d.b = (p1 >> 8) | (p2 << 16); d.c = (p2 >> 16) | (p3 << 8);\n"
+        "                *(mr_u3 *)q = d;\n"
+        "            } else {\n"
+        "                const unsigned pk[4] = {p0, p1, p2, p3};\n"
+        "                for (unsigned e = 0; e < 4u; e++)\n"
+        "                    if (xa + e < w) { q[3 * e] = (unsigned char)pk[e]; q[3 * e + 1] = (unsigned char)(pk[e] >> 8); q[3 * e + 2] = (unsigned char)(pk[e] >> 16); }\n"
+        "            }\n"
+        "        }\n"
+        "    } else {\n"
+        "        const unsigned pk[4] = {p0, p1, p2, p3};\n"
+        "        const double c0[4] = {o0.a, o0.b, o0.c, o0.d}, c1[4] = {o1.a, o1.b, o1.c, o1.d}, c2[4] = {o2.a, o2.b, o2.c, o2.d};\n"
+        "        _Pragma(\"unroll\") for (unsigned e = 0; e < 4u; e++)\n"
+        "            mr_store_run(rgb8, rgb64, row_px, x0 + 64u * e, w, mr_lane, mr_src, mr_shift, pk[e], c0[e], c1[e], c2[e]);\n"
+        "    }\n"
+        "    }\n";
+    // one 64-pixel run: f64 planes (24 B per lane) and / or RGB8 (48 lanes assemble a dword each from two neighbours'
+    // packed colours; ragged ends and unaligned rows store bytes)
+    const std::string store_run =
+        "__device__ inline void mr_store_run(unsigned char *__restrict__ rgb8, double *__restrict__ rgb64, size_t row_px, unsigned xw, unsigned w,\n"
+        "                                    unsigned lane, unsigned src, unsigned shift, unsigned pk, double c0, double c1, double c2)\n{\n"
+        "    const unsigned x = xw + lane;\n"
+        "    if (rgb64 && x < w) { const size_t p = (row_px + x) * 3; rgb64[p] = c0; rgb64[p + 1] = c1; rgb64[p + 2] = c2; }\n"
+        "    if (rgb8) {\n"
+        "        unsigned char *wave_out = rgb8 + (row_px + xw) * 3;\n"
+        "        if (xw + 64u <= w && ((size_t)wave_out & 3u) == 0u) {                // wave-uniform\n"
+        "            const unsigned pa = (unsigned)__builtin_amdgcn_ds_bpermute((int)(src * 4u), (int)pk);\n"
+        "            const unsigned pb = (unsigned)__builtin_amdgcn_ds_bpermute((int)(src * 4u + 4u), (int)pk);\n"
+        "            const unsigned dw = (unsigned)((((unsigned long long)pb << 24) | pa) >> shift);\n"
+        "            if (lane < 48u) ((unsigned *)wave_out)[lane] = dw;\n"
+        "        } else if (x < w) {\n"
+        "            unsigned char *q = rgb8 + (row_px + x) * 3;\n"
+        "            q[0] = (unsigned char)pk; q[1] = (unsigned char)(pk >> 8); q[2] = (unsigned char)(pk >> 16);\n"
+        "        }\n"
+        "    }\n"
+        "}\n";
+    std::string tile_end;         // closes a tile: the work list entry of a tile some Sin of which needs the slow path
+    if (defer)
+        tile_end = "    if (mr_slow_tile && mr_lane == 0u) tile_list[1u + atomicAdd(&tile_list[0], 1u)] = tile_base + r * n_tx + tile0 + t;\n";
+
     if (n_gwords) {
+        // the variant of a tile with no guard bit set, four pixels per lane
         if (n_gwords <= 12) {
             std::string any = "gq0";
             for (uint32_t j = 1; j < n_gwords; j++) any += " | gq" + std::to_string(j);
@@ -609,72 +790,77 @@ static std::string jit_source_px4(const maray_program &P, int min_waves_arg)
                  "    for (unsigned i = 0; i < " + nw + "u; i++) mr_any_g |= mr_gqt[i];\n"
                  "    if (mr_any_g == 0ull) {\n";
         }
+        E.td = "mr_d"; E.tm = "mr_m";
         E.assume_guards_zero = true;
+        s += deal + wide_open;
         E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+        s += wide_close;
         E.assume_guards_zero = false;
-        s += "    } else {\n";
+        s += tile_end + "    }\n    continue;\n    }\n";
+    }
+    if (wide_general) {
+        E.td = "mr_d"; E.tm = "mr_m";
+        s += deal + wide_open;
         E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
-        s += "    }\n";
-    } else
-        E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+        s += wide_close + tile_end + "    }\n";
+    } else {
+        E.td = "double"; E.tm = "mr_mask";
+        if (coop) {
+            s += "    {                                                                       // this wavefront's 64-pixel run of the tile\n" + opaque + gq_pass +
+                 "    const unsigned xw = x0 + 64u * mr_wv, x = xw + mr_lane;\n"
+                 "    const double X = (double)x;\n"
+                 "    double o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"
+                 "    float mr_defer = 0.0f;\n"
+                 "    (void)X; (void)mr_defer;\n";
+            E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+            s += defer_pass +
+                 "    const unsigned pk = mr_cast_u8(o0) | (mr_cast_u8(o1) << 8) | (mr_cast_u8(o2) << 16);\n"
+                 "    mr_store_run(rgb8, rgb64, row_px, xw, w, mr_lane, mr_src, mr_shift, pk, o0, o1, o2);\n"
+                 "    }\n" + tile_end;
+        } else {
+            // one wavefront, four passes of 64 pixels (a loop, not unrolled); the passes leave their packed pixels in LDS
+            // (same-wave traffic: no barrier) and a whole aligned tile is stored as a dwordx3 per lane
+            s += "    const bool mr_fast = rgb8 && x0 + 256u <= w && ((size_t)(rgb8 + (row_px + x0) * 3) & 3u) == 0u;      // wave-uniform\n"
+                 "    _Pragma(\"unroll 1\") for (unsigned e = 0; e < 4u; e++) {\n" + opaque + gq_pass +
+                 "    const unsigned xw = x0 + 64u * e, x = xw + mr_lane;\n"
+                 "    const double X = (double)x;\n"
+                 "    double o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"
+                 "    float mr_defer = 0.0f;\n"
+                 "    (void)X; (void)mr_defer;\n";
+            E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+            s += defer_pass +
+                 "    const unsigned pk = mr_cast_u8(o0) | (mr_cast_u8(o1) << 8) | (mr_cast_u8(o2) << 16);\n"
+                 "    if (mr_fast) {\n"
+                 "        mr_tp[mr_wv * 256u + 64u * e + mr_lane] = pk;\n"
+                 "        mr_store_run(nullptr, rgb64, row_px, xw, w, mr_lane, mr_src, mr_shift, pk, o0, o1, o2);\n"
+                 "    } else mr_store_run(rgb8, rgb64, row_px, xw, w, mr_lane, mr_src, mr_shift, pk, o0, o1, o2);\n"
+                 "    }\n"
+                 "    if (mr_fast) {\n"
+                 "        __builtin_amdgcn_wave_barrier();                                     // same wavefront wrote them: LDS keeps its order\n"
+                 "        const mr_u4 p = *(const mr_u4 *)&mr_tp[mr_wv * 256u + 4u * mr_lane];\n"
+                 "        mr_u3 d;\n"
+                 "        d.a = p.a | (p.b << 24); d.b = (p.b >> 8) | (p.c << 16); d.c = (p.c >> 16) | (p.d << 8);\n"
+                 "        *(mr_u3 *)(rgb8 + (row_px + x0 + 4u * mr_lane) * 3) = d;\n"
+                 "        __builtin_amdgcn_wave_barrier();\n"
+                 "    }\n" + tile_end;
+        }
+    }
+    s += "    }\n}\n";
     {
-        std::string tab;
+        std::string tab = store_run;
         if (!E.ktab_vals.empty()) {
-            tab = "__constant__ double mr_kc_tab[" + std::to_string(E.ktab_vals.size()) + "] = {";
+            tab += "__constant__ double mr_kc_tab[" + std::to_string(E.ktab_vals.size()) + "] = {";
             for (size_t j = 0; j < E.ktab_vals.size(); j++) { tab += (j % 6 ? " " : "\n    "); tab += lit(E.ktab_vals[j]); tab += ","; }
             tab += "\n};\n";
         }
         s.replace(s.find("/*MR_KTAB*/"), 11, tab);
-        s.replace(s.find("/*MR_KBASE*/"), 12, E.ktab_vals.empty() ? "    asm volatile(\"\" ::: \"memory\");\n" :
-                  "    unsigned long long mr_kbase = (unsigned long long)mr_kc_tab;\n"
-                  "    asm volatile(\"\" : \"+s\"(mr_kbase) :: \"memory\");\n"
-                  "    const mr_kptr mr_kc = (mr_kptr)mr_kbase;\n");
+        // The table's address, made opaque once per tile and once per pass (see `opaque`)
+        s.replace(s.find("/*MR_KBASE*/"), 12, E.ktab_vals.empty() ? "" : "    unsigned long long mr_kbase = (unsigned long long)mr_kc_tab;\n");
+        const std::string kc = E.ktab_vals.empty() ? "    asm volatile(\"\" ::: \"memory\");\n" :
+                               "    asm volatile(\"\" : \"+s\"(mr_kbase) :: \"memory\");\n"
+                               "    const mr_kptr mr_kc = (mr_kptr)mr_kbase;\n";
+        for (size_t at; (at = s.find("/*MR_KC*/")) != std::string::npos;) s.replace(at, 9, kc);
     }
-    if (defer)
-        s += "    if (mr_ballot(mr_defer != 0.0f) != 0ull || ((volatile unsigned *)mr_slow)[mr_wv] != 0u) {      // wave-uniform\n"
-             "        if (mr_lane == 0u) tile_list[1u + atomicAdd(&tile_list[0], 1u)] = tile_base + r * n_tx + tile0 + t;\n"
-             "    }\n";
-    // outputs
-    s += "    const unsigned p0 = mr_cast_u8(o0.a) | (mr_cast_u8(o1.a) << 8) | (mr_cast_u8(o2.a) << 16);\n"
-         "    const unsigned p1 = mr_cast_u8(o0.b) | (mr_cast_u8(o1.b) << 8) | (mr_cast_u8(o2.b) << 16);\n"
-         "    const unsigned p2 = mr_cast_u8(o0.c) | (mr_cast_u8(o1.c) << 8) | (mr_cast_u8(o2.c) << 16);\n"
-         "    const unsigned p3 = mr_cast_u8(o0.d) | (mr_cast_u8(o1.d) << 8) | (mr_cast_u8(o2.d) << 16);\n"
-         "    const size_t row_px = (size_t)r * w;\n"
-         "    if (mr_wide) {\n"
-         "        if (rgb8) {\n"
-         "            unsigned char *q = rgb8 + (row_px + xa) * 3;                      // this lane's 12 bytes\n"
-         "            if (x0 + 256u <= w && ((size_t)(rgb8 + (row_px + x0) * 3) & 3u) == 0u) {      // wave-uniform\n"
-         "                mr_u3 d;\n"
-         "                d.a = p0 | (p1 << 24); d.b = (p1 >> 8) | (p2 << 16); d.c = (p2 >> 16) | (p3 << 8);\n"
-         "                *(mr_u3 *)q = d;\n"
-         "            } else {\n"
-         "                const unsigned pk[4] = {p0, p1, p2, p3};\n"
-         "                for (unsigned e = 0; e < 4u; e++)\n"
-         "                    if (xa + e < w) { q[3 * e] = (unsigned char)pk[e]; q[3 * e + 1] = (unsigned char)(pk[e] >> 8); q[3 * e + 2] = (unsigned char)(pk[e] >> 16); }\n"
-         "            }\n"
-         "        }\n"
-         "    } else {\n"
-         "        const unsigned pk[4] = {p0, p1, p2, p3};\n"
-         "        const double c0[4] = {o0.a, o0.b, o0.c, o0.d}, c1[4] = {o1.a, o1.b, o1.c, o1.d}, c2[4] = {o2.a, o2.b, o2.c, o2.d};\n"
-         "        _Pragma(\"unroll\") for (unsigned e = 0; e < 4u; e++) {\n"
-         "            const unsigned xw = x0 + 64u * e, x = xw + mr_lane;          // first pixel of this element's 64-pixel run; this lane's pixel\n"
-         "            if (x < w) { const size_t p = (row_px + x) * 3; rgb64[p] = c0[e]; rgb64[p + 1] = c1[e]; rgb64[p + 2] = c2[e]; }\n"
-         "            if (rgb8) {\n"
-         "                unsigned char *wave_out = rgb8 + (row_px + xw) * 3;\n"
-         "                if (xw + 64u <= w && ((size_t)wave_out & 3u) == 0u) {                // wave-uniform\n"
-         "                    const unsigned pa = (unsigned)__builtin_amdgcn_ds_bpermute((int)(mr_src * 4u), (int)pk[e]);\n"
-         "                    const unsigned pb = (unsigned)__builtin_amdgcn_ds_bpermute((int)(mr_src * 4u + 4u), (int)pk[e]);\n"
-         "                    const unsigned dw = (unsigned)((((unsigned long long)pb << 24) | pa) >> mr_shift);\n"
-         "                    if (mr_lane < 48u) ((unsigned *)wave_out)[mr_lane] = dw;\n"
-         "                } else if (x < w) {\n"
-         "                    unsigned char *q = rgb8 + (row_px + x) * 3;\n"
-         "                    q[0] = (unsigned char)pk[e]; q[1] = (unsigned char)(pk[e] >> 8); q[2] = (unsigned char)(pk[e] >> 16);\n"
-         "                }\n"
-         "            }\n"
-         "        }\n"
-         "    }\n"
-         "    }\n"
-         "}\n";
     return s;
 }
 
@@ -687,9 +873,12 @@ static std::string jit_source_px4(const maray_program &P, int min_waves_arg)
 std::string jit_source(const maray_program &P, int min_waves_arg)
 {
     validate_program(P);
-    if (min_waves_arg == 0) min_waves_arg = jit_px() == 4 ? 4 : 8;
-    if (jit_px() == 4) return jit_source_px4(P, min_waves_arg);
+    // wave layout: 6, i.e. up to 102 SGPRs (at 8 the compiler gets 76 and spills ~400 of them to VGPR lanes, in the skeleton
+    // of bit tests and branches every pass walks; chess needs 38 VGPRs either way and runs 7 waves per SIMD)
+    if (min_waves_arg == 0) min_waves_arg = jit_px() == 4 ? 6 : 8;
+    if (jit_px() == 4) return jit_source_wave(P, min_waves_arg);
     Emitter E(P);
+    E.ybool = jit_bool_yvals(P);
     std::string &s = E.out;
     s += "// generated by libmaray_hip (jit_backend.cpp) from a v" + std::to_string(P.version) + " tape: PIXEL section, " +
          std::to_string(P.n_pix_ops) + " ops\n";
@@ -804,6 +993,7 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
         Emitter D(P);
         D.yv_name = E.yv_name;
         D.ignore_row_guards = true;
+        D.ybool = E.ybool;
         D.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
         E.bool_hint = D.is_bool_op;
     }
@@ -1020,10 +1210,7 @@ std::shared_ptr<const JitCode> build_code(const maray_program &prog, const CodeK
     std::string log;
     // Occupancy: the highest of 8 / 6 / 4 waves per SIMD (<= 64 / 80 / 128 VGPRs) whose build needs no scratch:
     // spilled VGPRs are HBM traffic.  MARAY_JIT_WAVES=<n> forces a build for n waves.
-    // Four pixels per lane: values are four times as wide and a build takes four times as long; the hint is then a
-    // ceiling the compiler is free to stay under (it reports what it used), 4 waves = 128 VGPRs, then 2 = 256.
-    const bool px4 = jit_px() == 4;
-    const int ladder[] = {px4 ? 4 : 8, px4 ? 2 : 6, px4 ? 1 : 4};
+    const int ladder[] = {jit_px() == 4 ? 6 : 8, jit_px() == 4 ? 4 : 6, jit_px() == 4 ? 2 : 4};
     for (int i = 0; i < 3; i++) {
         jit_compile(i == 0 ? k.src_pix : jit_source(prog, ladder[i]), c->pix, log);
         c->waves = ladder[i];
@@ -1096,13 +1283,19 @@ struct JitBackend final : Backend {
     unsigned *d_flags = nullptr; size_t flags_cap = 0;
     DevTex *d_tex = nullptr;
     std::vector<unsigned char *> d_tex_rgb;
-    double *d_yvals = nullptr; size_t yvals_cap = 0;
+    // ROW-stage tables, twice: launch k+1's ROW kernels (on row_stream) fill one set while launch k's PIXEL kernel (on the
+    // caller's stream) still reads the other.  row_done[b]: set b is written; pix_done[b]: its reader has finished.
+    double *d_yvals2[2] = {nullptr, nullptr}; size_t yvals_cap2[2] = {0, 0};
+    unsigned long long *d_gbits2[2] = {nullptr, nullptr}; size_t gbits_cap2[2] = {0, 0};
+    hipStream_t row_stream = nullptr;
+    hipEvent_t row_done[2] = {nullptr, nullptr}, pix_done[2] = {nullptr, nullptr};
+    bool row_done_set[2] = {false, false}, pix_done_set[2] = {false, false};
+    int cur_set = 0;
     unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;      // time_rows without a caller's buffer
     HostPipe pipe;                      // streams + staging of the host-raster entry points
     hipStream_t own_stream = nullptr;   // = pipe's compute stream
     uint32_t n_row_chunks = 1, n_gwords = 0, n_gjobs = 0, guard_rows = 1;
     uint32_t px = 4;                    // pixels per lane of the PIXEL kernel this context was built with
-    unsigned long long *d_gbits = nullptr; size_t gbits_cap = 0;
     bool has_sin = false;               // some Sin argument is not proven bounded: tiles may be deferred to `slow`
     hipStream_t last_stream = nullptr; bool have_last = false;      // the stream of the last launch (see launch())
     hipEvent_t handover = nullptr;
@@ -1115,8 +1308,13 @@ struct JitBackend final : Backend {
         (void)hipFree(d_flags);
         (void)hipFree(d_tex);
         for (auto p : d_tex_rgb) (void)hipFree(p);
-        (void)hipFree(d_gbits); (void)hipFree(d_order);
-        (void)hipFree(d_yvals); (void)hipFree(d_rgb8);
+        (void)hipFree(d_order); (void)hipFree(d_rgb8);
+        for (int b = 0; b < 2; b++) {
+            (void)hipFree(d_yvals2[b]); (void)hipFree(d_gbits2[b]);
+            if (row_done[b]) (void)hipEventDestroy(row_done[b]);
+            if (pix_done[b]) (void)hipEventDestroy(pix_done[b]);
+        }
+        if (row_stream) (void)hipStreamDestroy(row_stream);
         if (handover) (void)hipEventDestroy(handover);
     }
 
@@ -1133,7 +1331,7 @@ struct JitBackend final : Backend {
         HIP_TRY(hipModuleLoadData(&mod, code->pix.data()));
         HIP_TRY(hipModuleGetFunction(&f_pix, mod, "maray_jit_pixels"));
         n_row_chunks = code->n_row_chunks; n_gjobs = code->n_gjobs;
-        slow = make_tape_backend(dev, prog, tex, n_tex, false);
+        if (has_sin) slow = make_tape_backend(dev, prog, tex, n_tex, false);     // drains the tiles the pixel kernel defers; other programs never defer
         P = prog;
         P.consts = nullptr; P.row_ops = nullptr; P.pix_ops = nullptr;
         if (prog.n_row_ops) {
@@ -1147,6 +1345,11 @@ struct JitBackend final : Backend {
         pipe.init(dev);
         own_stream = pipe.compute_stream();
         HIP_TRY(hipEventCreateWithFlags(&handover, hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&row_stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) {
+            HIP_TRY(hipEventCreateWithFlags(&row_done[b], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&pix_done[b], hipEventDisableTiming));
+        }
         std::vector<DevTex> descs(n_tex ? n_tex : 1);
         for (uint32_t i = 0; i < n_tex; i++) {
             unsigned char *d = nullptr;
@@ -1184,26 +1387,38 @@ struct JitBackend final : Backend {
         // rows per guard evaluation: a group must not straddle two row blocks (its image rows have to be consecutive)
         unsigned yrows = (guard_rows > 1 && (blk_rows >= rows_total || blk_rows % guard_rows == 0)) ? guard_rows : 1u;
         const uint32_t n_groups = (rows_total + yrows - 1) / yrows;
-        ensure(d_yvals, yvals_cap, (size_t)rows_total * std::max<uint32_t>(P.n_yvals, 1));
-        {
-            const size_t had = gbits_cap;
-            ensure(d_gbits, gbits_cap, (size_t)n_groups * ((w + 255) / 256) * std::max<uint32_t>(n_gwords, 1));
+        // The ROW stage (y values, guard bits: ~15 us of latency-bound work on few wavefronts) runs on a stream of its own
+        // into the table set the previous launch is not reading, so that it overlaps that launch's PIXEL kernel; this
+        // launch's PIXEL kernel waits for it by event.  MARAY_JIT_ROW_OVERLAP=0: everything on the caller's stream.
+        const char *env_ov = getenv("MARAY_JIT_ROW_OVERLAP");
+        const bool overlap = !(env_ov && env_ov[0] == '0');
+        const int b = rows_pass ? (cur_set ^ 1) : cur_set;
+        hipStream_t rs = overlap ? row_stream : st;
+        if (rows_pass) {
+            if (pix_done_set[b]) HIP_TRY(hipStreamWaitEvent(rs, pix_done[b], 0));       // the reader of this set has finished
+            ensure(d_yvals2[b], yvals_cap2[b], (size_t)rows_total * std::max<uint32_t>(P.n_yvals, 1));
+            const size_t had = gbits_cap2[b];
+            ensure(d_gbits2[b], gbits_cap2[b], (size_t)n_groups * ((w + 255) / 256) * std::max<uint32_t>(n_gwords, 1));
             // bits past the last guard belong to no job and are never written: zero them once (the pixel kernel tests whole words)
-            if (gbits_cap != had) HIP_TRY(hipMemsetAsync(d_gbits, 0, gbits_cap * sizeof(unsigned long long), st));
+            if (gbits_cap2[b] != had) HIP_TRY(hipMemsetAsync(d_gbits2[b], 0, gbits_cap2[b] * sizeof(unsigned long long), rs));
+            cur_set = b;
         }
+        double *d_yvals = d_yvals2[b];
+        unsigned long long *d_gbits = d_gbits2[b];
+        if (!d_yvals || !d_gbits) throw Error{MARAY_E_INTERNAL, "launch without a ROW pass before any ROW pass"};
         unsigned n_yvals = P.n_yvals;
         if (rows_pass && P.n_row_ops) {
             unsigned yy0 = y0, rr = rows_total, ww = w;
             unsigned n_tx_ = (w + 255) / 256;
             // guards: one item per (group of yrows rows, 256-pixel tile); y values: one per row
             const uint64_t items = std::max<uint64_t>(n_gwords ? (uint64_t)n_groups * n_tx_ : 0, rows_total);
-            // Every job is a straight-line pass over its own code, executed once per wavefront: what bounds this kernel
-            // is instruction fetch, and the waves of one block share it.  MARAY_JIT_ROW_BLOCK: tuning knob.
             unsigned bs = 256;
-            if (const char *e_ = getenv("MARAY_JIT_ROW_BLOCK")) if (atoi(e_) >= 64 && atoi(e_) <= 256 && atoi(e_) % 64 == 0) bs = (unsigned)atoi(e_);
+            if (const char *e_ = getenv("MARAY_JIT_ROW_BLOCK")) if (atoi(e_) >= 64 && atoi(e_) <= 256 && atoi(e_) % 64 == 0) bs = (unsigned)atoi(e_);     // tuning knob
             if ((items + bs - 1) / bs > 0x7FFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
             void *args[] = {&d_yvals, &d_gbits, &d_tex, &yy0, &rr, &n_yvals, &ww, &n_tx_, &blk_rows, &blk_stride, &yrows};
-            HIP_TRY(hipModuleLaunchKernel(f_rows, (unsigned)((items + bs - 1) / bs), n_row_chunks + n_gjobs, 1, bs, 1, 1, 0, st, args, nullptr));
+            unsigned gy = n_row_chunks + n_gjobs;
+            if (const char *e_ = getenv("MARAY_JIT_ROW_PART")) if (e_[0] == '1') gy = n_row_chunks;       // measurement: y-value jobs only (wrong pixels!)
+            HIP_TRY(hipModuleLaunchKernel(f_rows, (unsigned)((items + bs - 1) / bs), gy, 1, bs, 1, 1, 0, rs, args, nullptr));
         }
         // launch order of the PIXEL kernel (maray_jit_order): once per geometry, from the guard bits the ROW kernel just wrote;
         // a cached order is used by every launch of that geometry, with or without a ROW pass (time_rows)
@@ -1213,14 +1428,21 @@ struct JitBackend final : Backend {
             const bool cached = key[0] == order_key[0] && key[1] == order_key[1] && key[2] == order_key[2];
             if (!cached && rows_pass) {
                 order_key[0] = order_key[1] = order_key[2] = 0;     // no geometry owns d_order until the kernel below is enqueued
+                // an earlier launch (another geometry) may still be reading the table: its pixel kernel first
+                if (pix_done_set[b ^ 1]) HIP_TRY(hipStreamWaitEvent(rs, pix_done[b ^ 1], 0));
                 ensure(d_order, order_cap, (size_t)rows_total);
                 unsigned rr = rows_total, n_tx_ = (w + 255) / 256;
                 void *oargs[] = {&d_gbits, &d_order, &rr, &n_tx_, &yrows};
-                HIP_TRY(hipModuleLaunchKernel(f_order, 1, 1, 1, 256, 1, 1, n_groups * 4, st, oargs, nullptr));
+                HIP_TRY(hipModuleLaunchKernel(f_order, 1, 1, 1, 256, 1, 1, n_groups * 4, rs, oargs, nullptr));
                 order_key[0] = key[0]; order_key[1] = key[1]; order_key[2] = key[2];
             }
             if (key[0] == order_key[0] && key[1] == order_key[1] && key[2] == order_key[2]) row_order = d_order;
         }
+        if (rows_pass && rs != st) {
+            HIP_TRY(hipEventRecord(row_done[b], rs));
+            row_done_set[b] = true;
+        }
+        if (row_done_set[b] && rs != st) HIP_TRY(hipStreamWaitEvent(st, row_done[b], 0));
         const unsigned n_tx = (w + 255) / 256;
         const uint64_t n_tiles = (uint64_t)n_tx * rows_total;
         // tiles per block: amortise the per-block prologue, but rows cost what they show (sky: nothing, board: 5x the
@@ -1228,18 +1450,21 @@ struct JitBackend final : Backend {
         // walking the rows in a scattered order to mix cheap and dear ones costs more in cache locality than it balances)
         unsigned tiles, gx;
         if (px == 4) {
-            // four pixels per lane: a wavefront owns `tiles` consecutive tiles of a row, a block four such strips
-            tiles = 2;
+            // a block (or, MARAY_JIT_LAYOUT=wave, a wavefront) owns `tiles` consecutive tiles of a row; a strip's guard
+            // words are one word per lane of a wavefront
+            const bool coop = jit_coop();
+            tiles = coop ? 8 : 2;
             if (const char *e_ = getenv("MARAY_JIT_TILES")) if (atoi(e_) > 0) tiles = (unsigned)std::min(64, atoi(e_));      // tuning knob
-            tiles = std::min(tiles, n_tx);
-            gx = (n_tx + 4 * tiles - 1) / (4 * tiles);
+            if (n_gwords && n_gwords <= 12) tiles = std::min(tiles, 64u / n_gwords);
+            tiles = std::max(1u, std::min(tiles, n_tx));
+            gx = coop ? (n_tx + tiles - 1) / tiles : (n_tx + 4 * tiles - 1) / (4 * tiles);
         } else {
             tiles = has_sin ? 1u : (unsigned)std::min<uint64_t>(std::min<uint64_t>(8, n_tx), std::max<uint64_t>(1, n_tiles / 4096));
             if (const char *e_ = getenv("MARAY_JIT_TILES")) if (!has_sin && atoi(e_) > 0) tiles = (unsigned)std::min(n_gwords > 12 ? 8 : 16, atoi(e_));      // tuning knob (the kernel stages guard words for <= 16 / 8 tiles)
             gx = (n_tx + tiles - 1) / tiles;
         }
         if (n_tiles > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
-        ensure(d_flags, flags_cap, (size_t)n_tiles + 1);                    // work list {count, tile, ...} of deferred tiles
+        ensure(d_flags, flags_cap, (size_t)n_tiles * 4 + 1);                // work list {count, tile, ...} of deferred tiles (each of a tile's four wavefronts may name it)
         if (has_sin) HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(unsigned), st));
         for (uint32_t r0 = 0; r0 < rows_total; r0 += 65535) {          // gridDim.y limit
             const uint32_t rows = std::min<uint32_t>(65535, rows_total - r0);
@@ -1254,6 +1479,8 @@ struct JitBackend final : Backend {
             HIP_TRY(hipModuleLaunchKernel(f_pix, gx, rows, 1, 256, 1, 1, 0, st, args, nullptr));
         }
         if (has_sin) slow->render_flagged(w, rb, d8, d64, st, d_flags, d_yvals);   // no-op unless a tile was deferred
+        HIP_TRY(hipEventRecord(pix_done[b], st));
+        pix_done_set[b] = true;
     }
 
     void render_device(uint32_t w, uint32_t, const RowBlocks &rb, void *d8, void *d64, void *stream) override {

@@ -437,20 +437,27 @@ def test_guards_per_group_of_rows_with_ragged_ranges(chess_bytes):
 
 
 def test_specialised_kernel_variants_selected_by_tuning_knobs(chess_bytes, monkeypatch):
-    """Paths the default build of chess does not take: y values staged in LDS instead of read by scalar loads, guards
-    compiled away, one tile per block, literal constants."""
+    """Paths the default build of chess does not take.  Of the default layout (a wavefront per 256-pixel tile): the block's
+    four wavefronts side by side on a busy tile, guard words by scalar loads, the whole section four pixels per lane, y
+    values all numeric, no private ROW stream, other strip lengths.  And the first layout (one pixel per lane throughout,
+    MARAY_JIT_PX=1) with its own knobs: y values staged in LDS, guards compiled away, one tile per block, literal constants."""
     g = json.load(open(os.path.join(GOLDEN, 'chess_1024.json')))
     tape = M.Scene(chess_bytes).lower()
-    for env in ({'MARAY_JIT_YLDS': '1'}, {'MARAY_JIT_ROW_GUARDS': '0'}, {'MARAY_JIT_TILES': '1'}, {'MARAY_JIT_KTAB': '0'},
-                {'MARAY_JIT_ROW_BLOCK': '64', 'MARAY_JIT_TILES': '3'}, {'MARAY_JIT_GLDS': '0'}, {'MARAY_JIT_ROWS_REVERSED': '1'}, {'MARAY_JIT_NO_ORDER': '1'}):
+    px1 = {'MARAY_JIT_PX': '1'}
+    for env in ({'MARAY_JIT_LAYOUT': 'coop'}, {'MARAY_JIT_LAYOUT': 'coop', 'MARAY_JIT_TILES': '3'}, {'MARAY_JIT_GW': 'sload'}, {'MARAY_JIT_WIDE': '1'},
+                {'MARAY_JIT_YBOOL': '0'}, {'MARAY_JIT_ROW_OVERLAP': '0'}, {'MARAY_JIT_TILES': '1'}, {'MARAY_JIT_TILES': '5', 'MARAY_JIT_ROW_BLOCK': '64'},
+                {'MARAY_JIT_ROW_GUARDS': '0'}, {'MARAY_JIT_KTAB': '0'}, {'MARAY_JIT_NO_ORDER': '1'}, {'MARAY_JIT_ROW_CHUNK_OPS': '300'},
+                px1, dict(px1, MARAY_JIT_YLDS='1'), dict(px1, MARAY_JIT_ROW_GUARDS='0'), dict(px1, MARAY_JIT_TILES='1'), dict(px1, MARAY_JIT_KTAB='0'),
+                dict(px1, MARAY_JIT_ROW_BLOCK='64', MARAY_JIT_TILES='3'), dict(px1, MARAY_JIT_GLDS='0'), dict(px1, MARAY_JIT_ROWS_REVERSED='1')):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         ctx = M.Context(tape, backend=M.BACKEND_JIT)
-        got8, _ = ctx.render_rows(1024, 1024, 0, 1024, want_f64=False)
+        got8, got64 = ctx.render_rows(1024, 1024, 0, 1024)
         ctx.close()
         for k in env:
             monkeypatch.delenv(k)
         assert hashlib.sha256(got8.tobytes()).hexdigest() == g['rgb8_sha256'], env
+        assert np.array_equal(np.minimum(got64, 255).astype(np.uint8), got8), env
 
 
 def test_interpreter_variants_selected_by_tuning_knobs(chess_bytes, monkeypatch):
