@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <future>
 #include <map>
 #include <memory>
@@ -95,6 +96,18 @@ std::string lit(double v)
 // block (every region result does) as a 0/1 VGPR and re-derives the mask with v_cmp, three VALU
 // ops per region on the path that skips it.  Bits of lanes that are not executing are garbage
 // (NOT sets them); they can only make a region run that could have been skipped.
+// Where each guard (a y value that only gates SKIP ops) lives in a tile's guard words.  A guard whose value is the OR of
+// other guards -- the bound of a group of shapes is max(bound of shape, bound of shape, ...), and hash-consing makes
+// those operands the very values that are OUT as the shapes' own guards -- gets no bit: its test in the PIXEL section
+// is "any of its members' bits", one s_and on the word.  Computed in the ROW kernel such a guard costs its members'
+// cones all over again (chess: 40 group guards = 54 % of the ROW kernel's work, and the dearest jobs: 2,300 ops in a
+// chain where a shape's guard has 100-200).
+struct GuardPlan {
+    uint32_t n_pos = 0;                          // bits in use
+    std::vector<int32_t> pos;                    // per guard: its bit, or -1: derived
+    std::vector<std::vector<uint32_t>> members;  // per derived guard: the bits it is the OR of
+};
+
 struct Emitter {
     enum Kind { DBL, BOOL, NEGBOOL };   // NEGBOOL: value is -(b) in {-0.0, -1.0}, b = the named mask
     struct Val {
@@ -125,6 +138,7 @@ struct Emitter {
     // shapes above -- into f64 code: three v_max, a v_cndmask and a v_cmp where one s_or_b64 does.
     std::vector<uint8_t> ybool;                 // PIXEL in: per y value; ROW out (dry run): what each OUT wrote
     std::vector<uint8_t> out_is_bool;
+    const GuardPlan *plan = nullptr;            // guard -> bit(s) (identity when null)
     int stage_first = -1;                       // ROW: >= 0: OUT k goes to LDS, ys[(k - stage_first) * 65 + lane] (jit_source_rows)
     std::string td = "double", tm = "mr_mask";  // types of a value / a boolean in the generated text ("mr_d" / "mr_m": four pixels per lane)
     std::vector<double> ktab_vals;
@@ -222,9 +236,23 @@ struct Emitter {
                 }
                 if (row_guard && !nz && guard_words && MARAY_REF_INDEX(gref) >= guard_first) {
                     // a row bound: one bit of a guard word that sits in an SGPR since the kernel's prologue
-                    const uint32_t k = MARAY_REF_INDEX(gref) - guard_first;
-                    cond = guard_words <= 12 ? "(gq" + std::to_string(k / 64) + " & (1ull << " + std::to_string(k % 64) + ")) != 0ull"
-                                             : "(mr_uniform64(mr_gqt[" + std::to_string(k / 64) + "]) & (1ull << " + std::to_string(k % 64) + ")) != 0ull";
+                    const uint32_t g = MARAY_REF_INDEX(gref) - guard_first;
+                    auto word = [&](uint32_t wi) { return guard_words <= 12 ? "gq" + std::to_string(wi) : "mr_uniform64(mr_gqt[" + std::to_string(wi) + "])"; };
+                    if (!plan || plan->pos[g] >= 0) {
+                        const uint32_t k = plan ? (uint32_t)plan->pos[g] : g;
+                        cond = "(" + word(k / 64) + " & (1ull << " + std::to_string(k % 64) + ")) != 0ull";
+                    } else {        // derived: any of its members' bits
+                        std::vector<uint64_t> m(guard_words, 0);
+                        for (uint32_t k : plan->members[g]) m[k / 64] |= 1ull << (k % 64);
+                        std::string any;
+                        for (uint32_t wi = 0; wi < guard_words; wi++)
+                            if (m[wi]) {
+                                char hex[32];
+                                snprintf(hex, sizeof hex, "0x%llxull", (unsigned long long)m[wi]);
+                                any += (any.empty() ? "(" : " | (") + word(wi) + " & " + hex + ")";
+                            }
+                        cond = "(" + (any.empty() ? std::string("0ull") : any) + ") != 0ull";
+                    }
                 } else if (row_guard) {
                     // a y value is uniform over the block: test its bits on the scalar unit, no ballot, no VALU
                     const std::string k = std::to_string(MARAY_REF_INDEX(gref));
@@ -247,8 +275,10 @@ struct Emitter {
             if (op == MARAY_OP_OUT) {
                 if (!pixel) { if (out_is_bool.size() <= aux) out_is_bool.resize(aux + 1, 0); out_is_bool[aux] = va->kind == BOOL; }
                 const std::string a = dbl(va, "m", i, 0);
-                if (!pixel && out_guard_bits && aux >= guard_first)
-                    out += "    gacc |= (" + a + " != 0.0) ? (1ull << " + std::to_string((aux - guard_first) % 8) + ") : 0ull;\n";
+                if (!pixel && out_guard_bits && aux >= guard_first) {
+                    const uint32_t k = plan ? (uint32_t)plan->pos[aux - guard_first] : aux - guard_first;     // (a derived guard has no job: its OUT is in no cone)
+                    out += "    gacc |= (" + a + " != 0.0) ? (1ull << " + std::to_string(k % 8) + ") : 0ull;\n";
+                }
                 else
                     out += pixel ? "    o" + std::to_string(aux) + " = " + a + ";\n"
                            : stage_first >= 0 ? "    ys[" + std::to_string((aux - (uint32_t)stage_first) * 65) + "u + mr_lane] = " + a + ";\n"
@@ -379,6 +409,71 @@ std::vector<uint8_t> jit_bool_yvals(const maray_program &P)
     return r;
 }
 
+// The guard plan of a program (GuardPlan).  A guard is derived when its source is a MAX tree, boolean-typed all the way
+// (on {+0.0, 1.0} max is OR, so "value != 0" distributes over it exactly), whose leaves are sources of other guards.
+// Bits are handed out in the order the members are met, so that a group's bits are neighbours (one word, one s_and).
+// MARAY_JIT_DERIVED=0: every guard gets its bit and its job (ablation).
+GuardPlan jit_guard_plan(const maray_program &P)
+{
+    GuardPlan gp;
+    const uint32_t n_ynum = numeric_yvals(P), n_guards = P.n_yvals - n_ynum;
+    gp.pos.assign(n_guards, -1);
+    gp.members.assign(n_guards, {});
+    const char *e_ = getenv("MARAY_JIT_DERIVED");
+    const bool derive = !(e_ && e_[0] == '0');
+    const RowTapeDeps d = row_tape_deps(P);
+    std::vector<int32_t> src(n_guards, -1);                    // op that produces a guard's value
+    std::unordered_map<int32_t, uint32_t> guard_of;            // op -> (first) guard it is the source of
+    for (uint32_t o : d.outs) {
+        const uint32_t aux = MARAY_INS_AUX(P.row_ops[o]);
+        if (aux < n_ynum) continue;
+        src[aux - n_ynum] = d.deps[o][0];
+        if (d.deps[o][0] >= 0) guard_of.emplace(d.deps[o][0], aux - n_ynum);
+    }
+    std::vector<uint8_t> isb;
+    if (derive && P.n_row_ops) {
+        Emitter D(P);
+        D.section(P.row_ops, P.n_row_ops, P.n_row_slots, false, "r");
+        isb = D.is_bool_op;
+    }
+    // leaves of guard g's MAX tree; false if it is not one
+    std::vector<std::vector<uint32_t>> kids(n_guards);
+    std::vector<uint8_t> derived(n_guards, 0);
+    for (uint32_t g = 0; g < n_guards && derive; g++) {
+        const int32_t s0 = src[g];
+        if (s0 < 0 || MARAY_INS_OP(P.row_ops[s0]) != MARAY_OP_MAX || !isb[s0]) continue;
+        std::vector<int32_t> st = {d.deps[s0][0], d.deps[s0][1]};
+        std::vector<uint32_t> leaves;
+        bool ok = true;
+        while (ok && !st.empty()) {
+            const int32_t o = st.back(); st.pop_back();
+            if (o < 0) { ok = false; break; }
+            auto it = guard_of.find(o);
+            if (it != guard_of.end() && it->second != g) { leaves.push_back(it->second); continue; }
+            if (MARAY_INS_OP(P.row_ops[o]) == MARAY_OP_MAX && isb[o]) { st.push_back(d.deps[o][1]); st.push_back(d.deps[o][0]); continue; }
+            ok = false;
+        }
+        if (ok && !leaves.empty() && leaves.size() <= 64) { derived[g] = 1; kids[g] = leaves; }
+    }
+    // bits: members of a derived guard first, in tree order (recursively: a member may be derived itself), then the rest
+    std::function<void(uint32_t, std::vector<uint32_t> &)> place = [&](uint32_t g, std::vector<uint32_t> &into) {
+        if (derived[g]) {
+            if (gp.members[g].empty()) for (uint32_t k : kids[g]) place(k, gp.members[g]);
+            into.insert(into.end(), gp.members[g].begin(), gp.members[g].end());
+            return;
+        }
+        if (gp.pos[g] < 0) gp.pos[g] = (int32_t)gp.n_pos++;
+        into.push_back((uint32_t)gp.pos[g]);
+    };
+    std::vector<uint32_t> sink;
+    // dearest groups first: their members end up contiguous
+    std::vector<uint32_t> order(n_guards);
+    for (uint32_t g = 0; g < n_guards; g++) order[g] = g;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return kids[a].size() > kids[b].size(); });
+    for (uint32_t g : order) { sink.clear(); place(g, sink); }
+    return gp;
+}
+
 // The ROW section split into chunks that different wavefronts evaluate side by side.  One
 // work-item per row is all the parallelism a straight-line ROW kernel has (4096 rows = 64 waves,
 // each walking thousands of dependent f64 ops: ~45 us for chess, an eighth of the frame).  The y
@@ -428,9 +523,9 @@ RowChunks split_row_tape(const maray_program &P, const RowTapeDeps &d, uint32_t 
 // words sit in SGPRs; beyond, a guard test reads its word from LDS.
 uint32_t jit_guard_words(const maray_program &P)
 {
-    const uint32_t n_guards = P.n_yvals - numeric_yvals(P);
-    const uint32_t nw = (n_guards + 63) / 64;
-    return (jit_row_guards_enabled() && nw <= 1024) ? nw : 0;       // 1024 words x 8 tiles = 64 KB of LDS
+    if (!jit_row_guards_enabled() || P.n_yvals == numeric_yvals(P)) return 0;
+    const uint32_t nw = (jit_guard_plan(P).n_pos + 63) / 64;
+    return nw <= 1024 ? std::max(nw, 1u) : 0;       // 1024 words x 8 tiles = 64 KB of LDS
 }
 
 // Rows per guard evaluation: 8 when no guard's cone reads Y (every guard then bounds its boolean over the rows
@@ -457,7 +552,8 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
     Emitter E(P);
     const RowTapeDeps deps = row_tape_deps(P);
     const uint32_t n_ynum = numeric_yvals(P), n_gwords = jit_guard_words(P);
-    const uint32_t n_gjobs = n_gwords ? (P.n_yvals - n_ynum + 7) / 8 : 0;       // 8 guards = one byte of a word per job
+    const GuardPlan plan = jit_guard_plan(P);
+    const uint32_t n_gjobs = n_gwords ? (plan.n_pos + 7) / 8 : 0;                // 8 bits = one byte of a word per job
     if (n_gjobs_out) *n_gjobs_out = n_gjobs;
     // the interpreter (which drains deferred tiles from the same y-value table) does read the guard values
     const uint32_t out_limit = may_defer_tiles(P) ? 0xFFFFFFFFu : n_ynum;
@@ -522,11 +618,14 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
              "    switch (blockIdx.y - " + std::to_string(chunks.size()) + "u) {\n";
         E.out_guard_bits = true;
         E.guard_first = n_ynum;
+        E.plan = &plan;
         for (uint32_t j = 0; j < n_gjobs; j++) {
-            std::vector<uint32_t> outs;
+            std::vector<uint32_t> outs;          // the guards whose bits are 8 j .. 8 j + 7 (derived guards have none: no job computes them)
             for (uint32_t o : deps.outs) {
                 const uint32_t aux = MARAY_INS_AUX(P.row_ops[o]);
-                if (aux >= n_ynum + 8 * j && aux < n_ynum + 8 * (j + 1)) outs.push_back(o);
+                if (aux < n_ynum) continue;
+                const int32_t k = plan.pos[aux - n_ynum];
+                if (k >= (int32_t)(8 * j) && k < (int32_t)(8 * (j + 1))) outs.push_back(o);
             }
             const std::vector<uint64_t> tape = row_tape_cone(P, deps, outs, nullptr);
             s += "    case " + std::to_string(j) + ": {\n";
@@ -610,7 +709,8 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
     const uint32_t n_ynum = numeric_yvals(P);
     const uint32_t n_gwords = jit_guard_words(P);
     E.ignore_row_guards = n_gwords == 0;
-    if (n_gwords) { E.guard_first = n_ynum; E.guard_words = n_gwords; }
+    const GuardPlan plan = jit_guard_plan(P);
+    if (n_gwords) { E.guard_first = n_ynum; E.guard_words = n_gwords; E.plan = &plan; }
     const bool defer = may_defer_tiles(P);
     const std::string nw = std::to_string(n_gwords);
     const bool coop = jit_coop();
@@ -898,7 +998,8 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
     // Without usable guard words (none, too many, or MARAY_JIT_ROW_GUARDS=0) those SKIP ops are compiled away.
     const uint32_t n_gwords = jit_guard_words(P);
     E.ignore_row_guards = n_gwords == 0;
-    if (n_gwords) { E.guard_first = n_ynum; E.guard_words = n_gwords; }
+    const GuardPlan plan = jit_guard_plan(P);
+    if (n_gwords) { E.guard_first = n_ynum; E.guard_words = n_gwords; E.plan = &plan; }
     if (y_lds) E.yv_name = "mr_ylds";
     if (y_lds) s += "__shared__ double mr_ylds[" + std::to_string(n_ynum) + "];\n";
     // MARAY_JIT_GLDS=0: the guard words of a tile by scalar loads issued one tile ahead, instead of staging the words of
@@ -1387,11 +1488,12 @@ struct JitBackend final : Backend {
         // rows per guard evaluation: a group must not straddle two row blocks (its image rows have to be consecutive)
         unsigned yrows = (guard_rows > 1 && (blk_rows >= rows_total || blk_rows % guard_rows == 0)) ? guard_rows : 1u;
         const uint32_t n_groups = (rows_total + yrows - 1) / yrows;
-        // The ROW stage (y values, guard bits: ~15 us of latency-bound work on few wavefronts) runs on a stream of its own
-        // into the table set the previous launch is not reading, so that it overlaps that launch's PIXEL kernel; this
-        // launch's PIXEL kernel waits for it by event.  MARAY_JIT_ROW_OVERLAP=0: everything on the caller's stream.
+        // MARAY_JIT_ROW_OVERLAP=1: the ROW stage (y values, guard bits: ~10 us of latency-bound work on few wavefronts) runs
+        // on a stream of its own into the table set the previous launch is not reading, so that it overlaps that launch's
+        // PIXEL kernel; this launch's PIXEL kernel waits for it by event.  Not the default: the two kernels then share the
+        // SIMDs, the PIXEL kernel slows down by what the ROW kernel saves (chess: 58.5 against 57.1 us per frame).
         const char *env_ov = getenv("MARAY_JIT_ROW_OVERLAP");
-        const bool overlap = !(env_ov && env_ov[0] == '0');
+        const bool overlap = env_ov && env_ov[0] == '1';
         const int b = rows_pass ? (cur_set ^ 1) : cur_set;
         hipStream_t rs = overlap ? row_stream : st;
         if (rows_pass) {

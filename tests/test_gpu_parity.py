@@ -445,7 +445,7 @@ def test_specialised_kernel_variants_selected_by_tuning_knobs(chess_bytes, monke
     tape = M.Scene(chess_bytes).lower()
     px1 = {'MARAY_JIT_PX': '1'}
     for env in ({'MARAY_JIT_LAYOUT': 'coop'}, {'MARAY_JIT_LAYOUT': 'coop', 'MARAY_JIT_TILES': '3'}, {'MARAY_JIT_GW': 'sload'}, {'MARAY_JIT_WIDE': '1'},
-                {'MARAY_JIT_YBOOL': '0'}, {'MARAY_JIT_ROW_OVERLAP': '0'}, {'MARAY_JIT_TILES': '1'}, {'MARAY_JIT_TILES': '5', 'MARAY_JIT_ROW_BLOCK': '64'},
+                {'MARAY_JIT_YBOOL': '0'}, {'MARAY_JIT_ROW_OVERLAP': '1'}, {'MARAY_JIT_DERIVED': '0'}, {'MARAY_JIT_TILES': '1'}, {'MARAY_JIT_TILES': '5', 'MARAY_JIT_ROW_BLOCK': '64'},
                 {'MARAY_JIT_ROW_GUARDS': '0'}, {'MARAY_JIT_KTAB': '0'}, {'MARAY_JIT_NO_ORDER': '1'}, {'MARAY_JIT_ROW_CHUNK_OPS': '300'},
                 px1, dict(px1, MARAY_JIT_YLDS='1'), dict(px1, MARAY_JIT_ROW_GUARDS='0'), dict(px1, MARAY_JIT_TILES='1'), dict(px1, MARAY_JIT_KTAB='0'),
                 dict(px1, MARAY_JIT_ROW_BLOCK='64', MARAY_JIT_TILES='3'), dict(px1, MARAY_JIT_GLDS='0'), dict(px1, MARAY_JIT_ROWS_REVERSED='1')):
