@@ -238,21 +238,24 @@ struct Emitter {
                     // a row bound: one bit of a guard word that sits in an SGPR since the kernel's prologue
                     const uint32_t g = MARAY_REF_INDEX(gref) - guard_first;
                     auto word = [&](uint32_t wi) { return guard_words <= 12 ? "gq" + std::to_string(wi) : "mr_uniform64(mr_gqt[" + std::to_string(wi) + "])"; };
+                    // tests on 32-bit halves of the words: s_and_b32 sets SCC and the branch follows (a 64-bit test is
+                    // s_and + s_cmp_u64 + the branch, on the unit that bounds the busy tiles)
+                    std::vector<uint64_t> m(guard_words, 0);
                     if (!plan || plan->pos[g] >= 0) {
                         const uint32_t k = plan ? (uint32_t)plan->pos[g] : g;
-                        cond = "(" + word(k / 64) + " & (1ull << " + std::to_string(k % 64) + ")) != 0ull";
-                    } else {        // derived: any of its members' bits
-                        std::vector<uint64_t> m(guard_words, 0);
-                        for (uint32_t k : plan->members[g]) m[k / 64] |= 1ull << (k % 64);
-                        std::string any;
-                        for (uint32_t wi = 0; wi < guard_words; wi++)
-                            if (m[wi]) {
-                                char hex[32];
-                                snprintf(hex, sizeof hex, "0x%llxull", (unsigned long long)m[wi]);
-                                any += (any.empty() ? "(" : " | (") + word(wi) + " & " + hex + ")";
-                            }
-                        cond = "(" + (any.empty() ? std::string("0ull") : any) + ") != 0ull";
-                    }
+                        m[k / 64] = 1ull << (k % 64);
+                    } else for (uint32_t k : plan->members[g]) m[k / 64] |= 1ull << (k % 64);       // derived: any of its members' bits
+                    std::string any;
+                    int terms = 0;
+                    for (uint32_t wi = 0; wi < guard_words; wi++)
+                        for (int half = 0; half < 2; half++) {
+                            const uint32_t bits = (uint32_t)(m[wi] >> (32 * half));
+                            if (!bits) continue;
+                            char hex[24];
+                            snprintf(hex, sizeof hex, "0x%xu", bits);
+                            any += std::string(terms++ ? " | " : "") + "((unsigned)" + (half ? "(" + word(wi) + " >> 32)" : word(wi)) + " & " + hex + ")";
+                        }
+                    cond = "(" + (any.empty() ? std::string("0u") : any) + ") != 0u";
                 } else if (row_guard) {
                     // a y value is uniform over the block: test its bits on the scalar unit, no ballot, no VALU
                     const std::string k = std::to_string(MARAY_REF_INDEX(gref));
@@ -701,6 +704,11 @@ bool jit_coop()
 static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
 {
     Emitter E(P);
+    // Wave-level SKIP ops over fewer than 24 ops are ignored: a busy tile is bound by the scalar unit (branches, bit tests,
+    // mask algebra: 0.59 SALU instructions per cycle and CU against 35 % VALU issue), and a short region's test and branch
+    // cost that unit more than its ops cost the vector one (chess board 111 -> 104 us per 16.7 Mpx; 8 / 12 / 16 / 24 / 40
+    // ops: 108 / 107 / 106 / 104 / 106).
+    E.min_region = 24;
     if (const char *e_ = getenv("MARAY_JIT_MIN_REGION")) E.min_region = (uint32_t)atoi(e_);
     E.ybool = jit_bool_yvals(P);
     std::string &s = E.out;
@@ -757,10 +765,11 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
          "    if (tile0 >= n_tx) return;\n"
          "    const unsigned r = row_order ? row_order[blockIdx.y] : blockIdx.y;     // row of this launch (dearest groups of rows first); row_base + r = row of the whole call\n"
          "    const unsigned long long mr_ybase0 = (unsigned long long)(yvals + (size_t)r * n_yvals);\n"
-         "    const double Y = (double)(y0 + ((row_base + r) / blk_rows) * blk_stride + (row_base + r) % blk_rows);     // -> image row (RowBlocks)\n"
+         "    // -> image row (RowBlocks); one range of rows (blk_stride == 0) needs no division, and yrows is 1 or 8\n"
+         "    const double Y = (double)(blk_stride == 0u ? y0 + row_base + r : y0 + ((row_base + r) / blk_rows) * blk_stride + (row_base + r) % blk_rows);\n"
          "    (void)Y; (void)tex; (void)gbits; (void)yrows; (void)tile_list; (void)tile_base;\n";
     if (n_gwords)
-        s += "    const unsigned long long mr_gbase0 = (unsigned long long)(gbits + ((size_t)((row_base + r) / yrows) * n_tx + tile0) * " + nw + "u);\n";
+        s += "    const unsigned long long mr_gbase0 = (unsigned long long)(gbits + ((size_t)((row_base + r) >> (yrows == 8u ? 3u : 0u)) * n_tx + tile0) * " + nw + "u);\n";
     if (gw_vgpr)
         s += "    const unsigned mr_gn = (n_tx - tile0 < tiles ? n_tx - tile0 : tiles) * " + nw + "u;       // <= 64: the host bounds `tiles`\n"
              "    const unsigned long long mr_gv = mr_lane < mr_gn ? ((const unsigned long long *)mr_gbase0)[mr_lane] : 0ull;\n";

@@ -1,0 +1,24 @@
+#!/bin/bash
+# tools/gpu_profile_r2.sh — everything DESIGN.md section 7 quotes, in one GPU call; summaries go to gpurun_out/ and from
+# there (tools/summarize_profile.py, by hand) into profiles/r2_*.
+set -o pipefail
+cd $GRAFT_REPO_ROOT
+python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -20 gpurun_out/build.log; exit 1; }
+echo "== bench (driver's command)"
+timeout -k 10 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_r2.json 2> gpurun_out/bench_r2.err || { tail -5 gpurun_out/bench_r2.err; exit 1; }
+tail -c 1500 gpurun_out/bench_r2.json
+export MARAY_CACHE_DIR=/tmp/maray_cache
+echo "== profile jit"
+bash tools/profile_bench.sh jit --cpu-seconds 0 --no-cold --no-e2e --steps 30 --warmup 5 > gpurun_out/profile_jit.log 2>&1 || { tail -5 gpurun_out/profile_jit.log; exit 1; }
+echo "== crops"
+bash tools/pmc_crop.sh board chess board > gpurun_out/crop_board.log 2>&1 || tail -3 gpurun_out/crop_board.log
+bash tools/pmc_crop.sh sky chess sky > gpurun_out/crop_sky.log 2>&1 || tail -3 gpurun_out/crop_sky.log
+bash tools/pmc_crop.sh allops allops x > gpurun_out/crop_allops.log 2>&1 || tail -3 gpurun_out/crop_allops.log
+bash tools/pmc_crop.sh radial radial x > gpurun_out/crop_radial.log 2>&1 || tail -3 gpurun_out/crop_radial.log
+echo "== ablations"
+timeout -k 10 900 python tools/exp_pixels.py "default:" "px1 (round-1 layout):MARAY_JIT_PX=1" "coop:MARAY_JIT_LAYOUT=coop" "wide general:MARAY_JIT_WIDE=1" "ybool off:MARAY_JIT_YBOOL=0" "derived off:MARAY_JIT_DERIVED=0" "gw sload:MARAY_JIT_GW=sload" "tiles 1:MARAY_JIT_TILES=1" "tiles 4:MARAY_JIT_TILES=4" "no order:MARAY_JIT_NO_ORDER=1" "row overlap:MARAY_JIT_ROW_OVERLAP=1" "ktab off:MARAY_JIT_KTAB=0" "row guards off:MARAY_JIT_ROW_GUARDS=0" "default again:" > gpurun_out/ablations_r2.jsonl 2> gpurun_out/ablations_r2.err; cat gpurun_out/ablations_r2.jsonl
+echo "== other configs"
+python tools/bench_configs.py > gpurun_out/other_configs_r2.json 2>/dev/null; head -c 600 gpurun_out/other_configs_r2.json
+echo "== interpreters"
+bash tools/profile_trace_only.sh tape_smem --backend tape-smem --cpu-seconds 0 --no-cold --no-e2e --steps 30 --warmup 5 | tail -6
+bash tools/profile_trace_only.sh tape_lds --backend tape --cpu-seconds 0 --no-cold --no-e2e --steps 10 --warmup 2 | tail -6
