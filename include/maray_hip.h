@@ -74,8 +74,14 @@ int maray_scene_fix_color(maray_scene *s);
 int maray_scene_rescale(maray_scene *s, uint32_t sx, uint32_t sy);
 /* `Expr::simplify` on each channel (src/lib.rs:601-604: constant_reduction at the root, src/constant_reduction.rs:9-185,
  * then the rewrite rules of src/simplify.rs:129-327).  Authoring-time, not on the render path; the reference applies it
- * before `save` (examples/chess.rs:43).  `compress` is not provided. */
+ * before `save` (examples/chess.rs:43). */
 int maray_scene_simplify(maray_scene *s);
+/* `Expr::compress` on each channel (src/lib.rs:610-614: `flatten`, src/compressor.rs:167-211, then the greedy
+ * Let-introducing loop of `compress`, :214-236, driven by the printed length of every candidate term exactly as the
+ * reference's `Display` prints it).  Changes no value.  n_vars3 (may be NULL): variables introduced per channel. */
+int maray_scene_compress(maray_scene *s, uint32_t *n_vars3);
+/* `format!("{}", color[c]).chars().count()` (impl Display for Expr, src/lib.rs:196-366): what compress weighs. */
+int maray_scene_display_len(maray_scene *s, int c, uint64_t *len);
 
 /* ---- lowering: Expr -> tape ---------------------------------------------------
  * Replaces what the reference does per pixel in `Expr::eval2` + `Cache`

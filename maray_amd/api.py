@@ -91,6 +91,8 @@ def lib():
         'maray_scene_fix_color': (C.c_int, [vp]),
         'maray_scene_rescale': (C.c_int, [vp, u32, u32]),
         'maray_scene_simplify': (C.c_int, [vp]),
+        'maray_scene_compress': (C.c_int, [vp, C.POINTER(u32)]),
+        'maray_scene_display_len': (C.c_int, [vp, C.c_int, u64p]),
         'maray_lower': (C.c_int, [vp, C.POINTER(LowerOpts), C.POINTER(vp)]),
         'maray_tape_free': (None, [vp]),
         'maray_tape_program': (C.c_int, [vp, C.POINTER(Program)]),
@@ -211,6 +213,18 @@ class Scene:
     def simplify(self):
         """Expr::simplify on each channel (authoring-time rewrite rules of the reference)."""
         _check(lib().maray_scene_simplify(self._h))
+
+    def compress(self):
+        """Expr::compress on each channel (authoring-time: names repeated sub-expressions); returns the variables introduced."""
+        n = (C.c_uint32 * 3)()
+        _check(lib().maray_scene_compress(self._h, n))
+        return list(n)
+
+    def display_len(self, c):
+        """Characters of the reference's printed form of channel c."""
+        n = C.c_uint64()
+        _check(lib().maray_scene_display_len(self._h, c, C.byref(n)))
+        return n.value
 
     def rescale(self, sx, sy):
         _check(lib().maray_scene_rescale(self._h, sx, sy))

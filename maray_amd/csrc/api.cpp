@@ -258,6 +258,19 @@ int maray_scene_simplify(maray_scene *s)
     return guard([&] { REQUIRE(s, "null argument"); run_big_stack([&] { scene_simplify(s->s); }); });
 }
 
+int maray_scene_compress(maray_scene *s, uint32_t *n_vars3)
+{
+    return guard([&] { REQUIRE(s, "null argument"); run_big_stack([&] { scene_compress(s->s, n_vars3); }); });
+}
+
+int maray_scene_display_len(maray_scene *s, int c, uint64_t *len)
+{
+    return guard([&] {
+        REQUIRE(s && len && c >= 0 && c < 3, "bad argument");
+        run_big_stack([&] { *len = scene_display_len(s->s, c); });
+    });
+}
+
 // ---- lowering -----------------------------------------------------------------
 int maray_lower(const maray_scene *s, const maray_lower_opts *opts, maray_tape **out)
 {

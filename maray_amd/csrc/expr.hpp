@@ -69,5 +69,8 @@ void scene_fix_color(Scene &s);                                          // var_
 void scene_rescale(Scene &s, uint32_t sx, uint32_t sy);
 // simplify.cpp
 void scene_simplify(Scene &s);                                           // Expr::simplify on each channel
+// compress.cpp
+void scene_compress(Scene &s, uint32_t n_vars[3]);                       // Expr::compress on each channel (n_vars: variables introduced; may be null)
+uint64_t scene_display_len(Scene &s, int c);                             // format!("{}", color[c]).chars().count()
 
 }   // namespace maray

@@ -6,7 +6,7 @@
 // restatement keeps the reference's rules, their order and their quirks (prime factors tried up to 17 only, a rule
 // that fires for `Neg` on the left but not on the right, ...), because its results are data -- `.maray` files are
 // written after it -- and the reference's own tests (`src/lib.rs:1288-1516`, `:1694-1720`) pin them.
-// Not on the render path: nothing here runs per pixel.  `compress` (the Let-introducing pass) is not restated.
+// Not on the render path: nothing here runs per pixel.  `compress` (the Let-introducing pass): compress.cpp.
 #include <cstdint>
 #include <utility>
 

@@ -38,8 +38,13 @@ def test_chess_uses_the_pure_bounded_step_sin(chess_bytes):
     text = C.string_at(src).decode()
     L.maray_free(src)
     assert text.count('mr_stepsin_bounded_m(') == 256 and 'mr_stepsin_fast(' not in text
-    assert text.count('const mr_m ') > 2500       # half of chess is boolean algebra on lane masks (SGPR pairs), four per value
-    assert text.count('mr_m bv') > 3600 and ' bool bv' not in text and ' bool v' not in text
+    assert text.count('const mr_mask ') > 2500       # half of chess is boolean algebra on lane masks (SGPR pairs)
+    assert text.count('mr_mask bv') > 3600 and ' bool bv' not in text and ' bool v' not in text
+    # the tile with no guard bit set is evaluated four pixels per lane; y values that are booleans are read as masks
+    assert 'const mr_d v' in text and text.count('mr_ym(yw, ') >= 64 and 'mr_min(' not in text and 'mr_max(' not in text
+    # a group's guard has no bit of its own: its test is a mask over its members' bits
+    import re
+    assert len(re.findall(r'\(unsigned\)\(?gq\d(?: >> 32\))? & 0x[0-9a-f]+u\)\) != 0u', text)) >= 160
 
 
 def test_row_section_is_cut_into_chunks(chess_bytes):
@@ -57,13 +62,18 @@ def test_row_section_is_cut_into_chunks(chess_bytes):
     text = C.string_at(src).decode()
     L.maray_free(src)
     rows_src, guards_src = text.split('// guards: (row group, tile)')
-    assert 2 <= k.value <= 16 and rows_src.count('    case ') == k.value
-    written = sorted(int(m) for m in re.findall(r'yout\[(\d+)\] = ', rows_src))
-    n_num = len(written)
-    assert written == list(range(n_num)) and 0 < n_num < tape.info['n_yvals']
+    assert 2 <= k.value <= 64 and rows_src.count('    case ') == k.value
+    # a chunk's values go to LDS ([value - first][row]) and leave as rows of the table: every operand y value once
+    first = [int(m) for m in re.findall(r'mr_k0 = (\d+)u; mr_kn = \d+u;', rows_src)]
+    count = [int(m) for m in re.findall(r'mr_k0 = \d+u; mr_kn = (\d+)u;', rows_src)]
+    assert len(first) == k.value and first[0] == 0 and all(first[i] + count[i] == first[i + 1] for i in range(k.value - 1)) and max(count) <= 16
+    n_num = first[-1] + count[-1]
+    assert 0 < n_num < tape.info['n_yvals'] and len(re.findall(r'    ys\[\d+u \+ mr_lane\] = ', rows_src)) == n_num
     n_guards = tape.info['n_yvals'] - n_num
-    assert len(re.findall(r'gacc \|= ', guards_src)) == n_guards and 'yout[' not in guards_src.split('switch')[1]
-    assert guards_src.count('    case ') == (n_guards + 7) // 8        # 8 guards per job: many short wavefronts
+    # guards that are the OR of other guards (a group of shapes) have no job; the others, 8 bits = one byte per job
+    n_bits = len(re.findall(r'gacc \|= ', guards_src))
+    assert 0 < n_bits < n_guards and n_bits >= 128 and 'ys[' not in guards_src.split('switch')[1]
+    assert guards_src.count('    case ') == (n_bits + 7) // 8
     assert 'XMIN' in guards_src and 'XMIN' not in rows_src.split('switch')[1]      # only guards depend on the span
     build(tape)        # compiles the ROW kernel as well
 
