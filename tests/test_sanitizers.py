@@ -37,3 +37,52 @@ def test_reader_and_lowering_under_asan_ubsan(tmp_path):
     out = subprocess.run([exe] + files, capture_output=True, text=True, env=env)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     assert 'lowered' in out.stdout
+
+
+def test_png_reader_with_crafted_headers_under_asan_ubsan(tmp_path):
+    """maray_png_read takes its sizes from the file (a texture named on the command line): an IHDR whose products
+    overflow, or that promises more scanlines than its IDAT can inflate to, is an error code -- never an out-of-bounds
+    access, an allocation the size of the lie, or an exception across the C boundary."""
+    import struct
+    import zlib
+
+    import numpy as np
+    csrc = os.path.join(ROOT, 'maray_amd', 'csrc')
+    exe = str(tmp_path / 'png_asan')
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-g', '-fsanitize=address,undefined', '-fno-sanitize-recover=all',
+                           '-I' + csrc, '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'native', 'png_asan.cpp'),
+                           os.path.join(csrc, 'png.cpp'), '-o', exe, '-lz'])
+
+    def chunk(kind, data):
+        return struct.pack('>I', len(data)) + kind + data + struct.pack('>I', zlib.crc32(kind + data) & 0xFFFFFFFF)
+
+    def png(w, h, depth, ctype, idat, interlace=0):
+        return (b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, depth, ctype, 0, 0, interlace)) +
+                chunk(b'IDAT', idat) + chunk(b'IEND', b''))
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (7, 5, 3), dtype=np.uint8)
+    raw = b''.join(b'\x00' + img[r].tobytes() for r in range(7))
+    small = zlib.compress(b'\x00' * 16)
+    files = {
+        'good_rgb.png': png(5, 7, 8, 2, zlib.compress(raw)),
+        'good_gray16.png': png(3, 2, 16, 0, zlib.compress(b''.join(b'\x01' + bytes(6) for _ in range(2)))),
+        'huge_w.png': png(0xFFFFFFFF, 2, 8, 2, small),                       # stride * h wraps in 32 bits, not in 64: refused by size
+        'huge_both.png': png(0xFFFFFFFF, 0xFFFFFFFF, 16, 6, small),          # (stride + 1) * h overflows 64 bits
+        'wrap_to_small.png': png(0x55555556, 3, 8, 2, small),                # w * 3 wraps to 2 in 32 bits
+        'lying_ihdr.png': png(4096, 4096, 8, 2, small),                      # plausible size, 16 bytes of pixels
+        'million.png': png(1 << 20, 1 << 20, 8, 2, small),
+        'truncated.png': png(5, 7, 8, 2, zlib.compress(raw))[:60],
+        'bad_filter.png': png(5, 7, 8, 2, zlib.compress(b'\x09' + raw[1:])),
+        'interlaced.png': png(5, 7, 8, 2, zlib.compress(raw), interlace=1),
+        'zero.png': png(0, 0, 8, 2, small),
+        'not_png.png': b'P6 5 7 255 ' + raw,
+    }
+    paths = []
+    for name, data in files.items():
+        p = str(tmp_path / name)
+        open(p, 'wb').write(data)
+        paths.append(p)
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=1:allocator_may_return_null=1:max_allocation_size_mb=4096',
+               UBSAN_OPTIONS='print_stacktrace=1')
+    out = subprocess.run([exe] + paths, capture_output=True, text=True, env=env)
+    assert out.returncode == 0 and 'png ok' in out.stdout, out.stdout[-2500:] + out.stderr[-3000:]

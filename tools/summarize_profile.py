@@ -22,14 +22,15 @@ def main():
     rnd = sys.argv[sys.argv.index('--round') + 1] if '--round' in sys.argv else 'r2'
     src = os.path.join(ROOT, 'gpurun_out', 'prof_' + tag)
     dst = os.path.join(ROOT, 'profiles', '%s_%s_chess4096_' % (rnd, tag))
-    stats = glob.glob(src + '/trace/*/*_kernel_stats.csv')[0]
+    newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)      # gpurun_out/ keeps earlier runs' files too
+    stats = newest(src + '/trace/*/*_kernel_stats.csv')
     shutil.copy(stats, dst + 'kernel_stats.csv')
     line = [l for l in open(src + '/bench_trace.json') if l.startswith('{')][-1]
     open(dst + 'bench_under_rocprof.json', 'w').write(line)
     bench = json.loads(line)
 
     avg, res, cmd_steps = {}, {}, None
-    for f in sorted(glob.glob(src + '/pmc_*/*/*_counter_collection.csv')):
+    for f in [newest(d + '/*/*_counter_collection.csv') for d in sorted(glob.glob(src + '/pmc_*')) if os.path.isdir(d)]:
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if kernel not in r['Kernel_Name']:
