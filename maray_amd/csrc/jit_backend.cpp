@@ -682,6 +682,15 @@ bool jit_coop()
     return e_ && !strcmp(e_, "coop");
 }
 
+// One wavefront per strip (default), or persistent wavefronts walking (row, strip) items at a stride (MARAY_JIT_PERSIST=1:
+// measured slower -- chess 55.9 against 44.1 us per frame, board 136 against 105: the loop-carried item state pushes the
+// kernel past its 102 SGPRs (322 spills) and a wavefront's items are no longer neighbours in the caches).
+bool jit_persist()
+{
+    const char *e_ = getenv("MARAY_JIT_PERSIST");
+    return !jit_coop() && e_ && e_[0] == '1';
+}
+
 // Source of the PIXEL kernel (default layout).  A block of four wavefronts owns `tiles` consecutive 256-pixel tiles
 // of one row (blockIdx.y) and walks them without staging or barriers: every wavefront reads a tile's guard words by
 // scalar loads and one scalar test picks the tile's variant:
@@ -722,6 +731,7 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
     const bool defer = may_defer_tiles(P);
     const std::string nw = std::to_string(n_gwords);
     const bool coop = jit_coop();
+    const bool persist = jit_persist();
     // a strip's guard words: one vector load per wavefront (lane i holds word i), then v_readlane per tile -- one memory
     // latency per strip instead of one per tile (MARAY_JIT_GW=sload: scalar loads per tile; measurement knob)
     const char *env_gw = getenv("MARAY_JIT_GW");
@@ -758,12 +768,23 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
          "                                                                    const unsigned long long *__restrict__ gbits, unsigned n_tx,\n"
          "                                                                    unsigned w, unsigned y0, unsigned n_yvals, unsigned tiles,\n"
          "                                                                    unsigned blk_rows, unsigned blk_stride, unsigned row_base, unsigned yrows,\n"
-         "                                                                    const unsigned *__restrict__ row_order)\n{\n"
+         "                                                                    const unsigned *__restrict__ row_order, unsigned rows, unsigned strip_shift)\n{\n"
          "    const unsigned mr_wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), mr_lane = threadIdx.x & 63u;\n"
-         + std::string(coop ? "    const unsigned tile0 = blockIdx.x * tiles;                              // this block's strip of the row\n"
-                            : "    const unsigned tile0 = (blockIdx.x * 4u + mr_wv) * tiles;               // this wavefront's strip of the row\n") +
+         "    (void)rows; (void)strip_shift;\n"
+         + std::string(persist ?
+           "    // Persistent wavefronts: the grid fills the device once and every wavefront walks the (row, strip) items w, w + W,\n"
+           "    // w + 2 W, ... of the launch, rows in launch order (dearest groups first): each wavefront meets every price band,\n"
+           "    // the launch ends on cheap items, and a wavefront's start-up and the drain of its stores are paid once, not per strip.\n"
+           "    const unsigned mr_strips = (n_tx + tiles - 1u) / tiles, mr_items = rows * mr_strips;\n"
+           "    for (unsigned mr_item = blockIdx.x * 4u + mr_wv; mr_item < mr_items; mr_item += gridDim.x * 4u) {\n"
+           "    const unsigned mr_slot = strip_shift != 0xffffffffu ? mr_item >> strip_shift : mr_item / mr_strips;\n"
+           "    const unsigned tile0 = (mr_item - mr_slot * mr_strips) * tiles;          // this item's strip of its row\n"
+           "    const unsigned r = row_order ? row_order[mr_slot] : mr_slot;             // row of this launch; row_base + r = row of the whole call\n"
+           : (coop ? "    const unsigned tile0 = blockIdx.x * tiles;                              // this block's strip of the row\n"
+                   : "    const unsigned tile0 = (blockIdx.x * 4u + mr_wv) * tiles;               // this wavefront's strip of the row\n")) +
+         (persist ? "" :
          "    if (tile0 >= n_tx) return;\n"
-         "    const unsigned r = row_order ? row_order[blockIdx.y] : blockIdx.y;     // row of this launch (dearest groups of rows first); row_base + r = row of the whole call\n"
+         "    const unsigned r = row_order ? row_order[blockIdx.y] : blockIdx.y;     // row of this launch (dearest groups of rows first); row_base + r = row of the whole call\n") +
          "    const unsigned long long mr_ybase0 = (unsigned long long)(yvals + (size_t)r * n_yvals);\n"
          "    // -> image row (RowBlocks); one range of rows (blk_stride == 0) needs no division, and yrows is 1 or 8\n"
          "    const double Y = (double)(blk_stride == 0u ? y0 + row_base + r : y0 + ((row_base + r) / blk_rows) * blk_stride + (row_base + r) % blk_rows);\n"
@@ -954,7 +975,7 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
                  "    }\n" + tile_end;
         }
     }
-    s += "    }\n}\n";
+    s += persist ? "    }\n    }\n}\n" : "    }\n}\n";
     {
         std::string tab = store_run;
         if (!E.ktab_vals.empty()) {
@@ -1032,7 +1053,7 @@ std::string jit_source(const maray_program &P, int min_waves_arg)
          "                                                                    const unsigned long long *__restrict__ gbits, unsigned n_tx,\n"
          "                                                                    unsigned w, unsigned y0, unsigned n_yvals, unsigned tiles,\n"
          "                                                                    unsigned blk_rows, unsigned blk_stride, unsigned row_base, unsigned yrows,\n"
-         "                                                                    const unsigned *__restrict__ row_order)\n{\n"
+         "                                                                    const unsigned *__restrict__ row_order, unsigned, unsigned)\n{\n"
          // MARAY_JIT_ROWS_REVERSED (ablation): last rows first.  For chess (board at the bottom) the dear blocks then start
          // first and the launch's tail is sky: 71 -> 68 us per frame, i.e. the tail costs ~4 us.  Not general, not the default.
          + std::string(getenv("MARAY_JIT_ROWS_REVERSED") ? "    const unsigned r = gridDim.y - 1u - blockIdx.y;\n" : "    const unsigned r = row_order ? row_order[blockIdx.y] : blockIdx.y;     // row of this launch (dearest groups of rows first); row_base + r = row of the whole call\n") +
@@ -1405,6 +1426,7 @@ struct JitBackend final : Backend {
     HostPipe pipe;                      // streams + staging of the host-raster entry points
     hipStream_t own_stream = nullptr;   // = pipe's compute stream
     uint32_t n_row_chunks = 1, n_gwords = 0, n_gjobs = 0, guard_rows = 1;
+    uint32_t n_cu = 256;
     uint32_t px = 4;                    // pixels per lane of the PIXEL kernel this context was built with
     bool has_sin = false;               // some Sin argument is not proven bounded: tiles may be deferred to `slow`
     hipStream_t last_stream = nullptr; bool have_last = false;      // the stream of the last launch (see launch())
@@ -1435,6 +1457,7 @@ struct JitBackend final : Backend {
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
             throw Error{MARAY_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only"};
+        n_cu = (uint32_t)std::max(1, prop.multiProcessorCount);
         has_sin = may_defer_tiles(prog);
         px = jit_px();
         code = jit_code_for(prog);                       // built by the first context of the process, or read from the cache
@@ -1577,16 +1600,33 @@ struct JitBackend final : Backend {
         if (n_tiles > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
         ensure(d_flags, flags_cap, (size_t)n_tiles * 4 + 1);                // work list {count, tile, ...} of deferred tiles (each of a tile's four wavefronts may name it)
         if (has_sin) HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(unsigned), st));
+        if (px == 4 && jit_persist()) {
+            // persistent wavefronts: one launch whatever the number of rows, the grid sized to fill the device once
+            const unsigned strips = (n_tx + tiles - 1) / tiles;
+            const uint64_t items = (uint64_t)strips * rows_total;
+            if (items > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
+            unsigned per_cu = 7;
+            if (const char *e_ = getenv("MARAY_JIT_BLOCKS_PER_CU")) if (atoi(e_) > 0) per_cu = (unsigned)atoi(e_);      // tuning knob
+            const unsigned blocks = (unsigned)std::min<uint64_t>((items + 3) / 4, (uint64_t)n_cu * per_cu);
+            unsigned shift = 0xFFFFFFFFu;
+            for (unsigned k = 0; k < 31; k++) if (strips == (1u << k)) shift = k;
+            unsigned ww = w, yy0 = y0, tile_base = 0, row_base = 0, rr = rows_total, ntx = n_tx;
+            const unsigned long long *gb = d_gbits;
+            unsigned *fl = d_flags;
+            const double *yv = d_yvals;
+            void *args[] = {&d8, &d64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles, &blk_rows, &blk_stride, &row_base, &yrows, &row_order, &rr, &shift};
+            HIP_TRY(hipModuleLaunchKernel(f_pix, blocks, 1, 1, 256, 1, 1, 0, st, args, nullptr));
+        } else
         for (uint32_t r0 = 0; r0 < rows_total; r0 += 65535) {          // gridDim.y limit
             const uint32_t rows = std::min<uint32_t>(65535, rows_total - r0);
             unsigned char *p8 = d8 ? d8 + (size_t)r0 * w * 3 : nullptr;
             double *p64 = d64 ? d64 + (size_t)r0 * w * 3 : nullptr;
             const double *yv = d_yvals + (size_t)r0 * n_yvals;
             unsigned *fl = d_flags;
-            unsigned ww = w, yy0 = y0, tile_base = r0 * (px == 4 ? n_tx : gx), row_base = r0;
+            unsigned ww = w, yy0 = y0, tile_base = r0 * (px == 4 ? n_tx : gx), row_base = r0, rr = rows, shift = 0xFFFFFFFFu;
             const unsigned long long *gb = d_gbits;              // indexed by the row of the whole call
             unsigned ntx = n_tx;
-            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles, &blk_rows, &blk_stride, &row_base, &yrows, &row_order};
+            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles, &blk_rows, &blk_stride, &row_base, &yrows, &row_order, &rr, &shift};
             HIP_TRY(hipModuleLaunchKernel(f_pix, gx, rows, 1, 256, 1, 1, 0, st, args, nullptr));
         }
         if (has_sin) slow->render_flagged(w, rb, d8, d64, st, d_flags, d_yvals);   // no-op unless a tile was deferred
