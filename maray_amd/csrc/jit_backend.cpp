@@ -1312,6 +1312,7 @@ void cache_write(const std::string &dir, const std::string &path, const JitCode 
 
 std::mutex g_code_mutex;
 std::map<std::string, std::shared_future<std::shared_ptr<const JitCode>>> g_code;
+std::vector<std::string> g_code_order;              // oldest first: the table keeps the 32 most recent programs (the rest live on disk)
 
 struct CodeKey { std::string hex, src_pix, src_rows; uint32_t n_row_chunks = 1, n_gjobs = 0; };
 
@@ -1378,7 +1379,14 @@ std::shared_ptr<const JitCode> jit_code_for(const maray_program &prog)
         std::lock_guard<std::mutex> lk(g_code_mutex);
         auto it = g_code.find(k.hex);
         if (it != g_code.end()) fut = it->second;
-        else { fut = mine.get_future().share(); g_code.emplace(k.hex, fut); build = true; }
+        else {
+            fut = mine.get_future().share(); g_code.emplace(k.hex, fut); build = true;
+            g_code_order.push_back(k.hex);
+            while (g_code_order.size() > 32) {          // contexts hold their code objects themselves (shared_ptr)
+                g_code.erase(g_code_order.front());
+                g_code_order.erase(g_code_order.begin());
+            }
+        }
     }
     if (build) {
         try { mine.set_value(build_code(prog, k)); }
@@ -1427,6 +1435,9 @@ struct JitBackend final : Backend {
     hipStream_t own_stream = nullptr;   // = pipe's compute stream
     uint32_t n_row_chunks = 1, n_gwords = 0, n_gjobs = 0, guard_rows = 1;
     uint32_t n_cu = 256;
+    // launch-time tuning knobs, read once when the context is created
+    bool k_overlap = false, k_coop = false, k_persist = false, k_rows_chunks_only = false;
+    unsigned k_row_block = 256, k_tiles = 0, k_per_cu = 7;
     uint32_t px = 4;                    // pixels per lane of the PIXEL kernel this context was built with
     bool has_sin = false;               // some Sin argument is not proven bounded: tiles may be deferred to `slow`
     hipStream_t last_stream = nullptr; bool have_last = false;      // the stream of the last launch (see launch())
@@ -1460,6 +1471,12 @@ struct JitBackend final : Backend {
         n_cu = (uint32_t)std::max(1, prop.multiProcessorCount);
         has_sin = may_defer_tiles(prog);
         px = jit_px();
+        k_coop = jit_coop(); k_persist = jit_persist();
+        if (const char *e_ = getenv("MARAY_JIT_ROW_OVERLAP")) k_overlap = e_[0] == '1';
+        if (const char *e_ = getenv("MARAY_JIT_ROW_BLOCK")) if (atoi(e_) >= 64 && atoi(e_) <= 256 && atoi(e_) % 64 == 0) k_row_block = (unsigned)atoi(e_);
+        if (const char *e_ = getenv("MARAY_JIT_ROW_PART")) k_rows_chunks_only = e_[0] == '1';       // measurement: y-value jobs only (wrong pixels!)
+        if (const char *e_ = getenv("MARAY_JIT_TILES")) if (atoi(e_) > 0) k_tiles = (unsigned)atoi(e_);
+        if (const char *e_ = getenv("MARAY_JIT_BLOCKS_PER_CU")) if (atoi(e_) > 0) k_per_cu = (unsigned)atoi(e_);
         code = jit_code_for(prog);                       // built by the first context of the process, or read from the cache
         HIP_TRY(hipModuleLoadData(&mod, code->pix.data()));
         HIP_TRY(hipModuleGetFunction(&f_pix, mod, "maray_jit_pixels"));
@@ -1524,8 +1541,7 @@ struct JitBackend final : Backend {
         // on a stream of its own into the table set the previous launch is not reading, so that it overlaps that launch's
         // PIXEL kernel; this launch's PIXEL kernel waits for it by event.  Not the default: the two kernels then share the
         // SIMDs, the PIXEL kernel slows down by what the ROW kernel saves (chess: 58.5 against 57.1 us per frame).
-        const char *env_ov = getenv("MARAY_JIT_ROW_OVERLAP");
-        const bool overlap = env_ov && env_ov[0] == '1';
+        const bool overlap = k_overlap;
         const int b = rows_pass ? (cur_set ^ 1) : cur_set;
         hipStream_t rs = overlap ? row_stream : st;
         if (rows_pass) {
@@ -1546,12 +1562,11 @@ struct JitBackend final : Backend {
             unsigned n_tx_ = (w + 255) / 256;
             // guards: one item per (group of yrows rows, 256-pixel tile); y values: one per row
             const uint64_t items = std::max<uint64_t>(n_gwords ? (uint64_t)n_groups * n_tx_ : 0, rows_total);
-            unsigned bs = 256;
-            if (const char *e_ = getenv("MARAY_JIT_ROW_BLOCK")) if (atoi(e_) >= 64 && atoi(e_) <= 256 && atoi(e_) % 64 == 0) bs = (unsigned)atoi(e_);     // tuning knob
+            const unsigned bs = k_row_block;
             if ((items + bs - 1) / bs > 0x7FFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
             void *args[] = {&d_yvals, &d_gbits, &d_tex, &yy0, &rr, &n_yvals, &ww, &n_tx_, &blk_rows, &blk_stride, &yrows};
             unsigned gy = n_row_chunks + n_gjobs;
-            if (const char *e_ = getenv("MARAY_JIT_ROW_PART")) if (e_[0] == '1') gy = n_row_chunks;       // measurement: y-value jobs only (wrong pixels!)
+            if (k_rows_chunks_only) gy = n_row_chunks;
             HIP_TRY(hipModuleLaunchKernel(f_rows, (unsigned)((items + bs - 1) / bs), gy, 1, bs, 1, 1, 0, rs, args, nullptr));
         }
         // launch order of the PIXEL kernel (maray_jit_order): once per geometry, from the guard bits the ROW kernel just wrote;
@@ -1586,27 +1601,26 @@ struct JitBackend final : Backend {
         if (px == 4) {
             // a block (or, MARAY_JIT_LAYOUT=wave, a wavefront) owns `tiles` consecutive tiles of a row; a strip's guard
             // words are one word per lane of a wavefront
-            const bool coop = jit_coop();
+            const bool coop = k_coop;
             tiles = coop ? 8 : 2;
-            if (const char *e_ = getenv("MARAY_JIT_TILES")) if (atoi(e_) > 0) tiles = (unsigned)std::min(64, atoi(e_));      // tuning knob
+            if (k_tiles) tiles = std::min(64u, k_tiles);
             if (n_gwords && n_gwords <= 12) tiles = std::min(tiles, 64u / n_gwords);
             tiles = std::max(1u, std::min(tiles, n_tx));
             gx = coop ? (n_tx + tiles - 1) / tiles : (n_tx + 4 * tiles - 1) / (4 * tiles);
         } else {
             tiles = has_sin ? 1u : (unsigned)std::min<uint64_t>(std::min<uint64_t>(8, n_tx), std::max<uint64_t>(1, n_tiles / 4096));
-            if (const char *e_ = getenv("MARAY_JIT_TILES")) if (!has_sin && atoi(e_) > 0) tiles = (unsigned)std::min(n_gwords > 12 ? 8 : 16, atoi(e_));      // tuning knob (the kernel stages guard words for <= 16 / 8 tiles)
+            if (k_tiles && !has_sin) tiles = std::min(n_gwords > 12 ? 8u : 16u, k_tiles);      // (the kernel stages guard words for <= 16 / 8 tiles)
             gx = (n_tx + tiles - 1) / tiles;
         }
         if (n_tiles > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
         ensure(d_flags, flags_cap, (size_t)n_tiles * 4 + 1);                // work list {count, tile, ...} of deferred tiles (each of a tile's four wavefronts may name it)
         if (has_sin) HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(unsigned), st));
-        if (px == 4 && jit_persist()) {
+        if (px == 4 && k_persist) {
             // persistent wavefronts: one launch whatever the number of rows, the grid sized to fill the device once
             const unsigned strips = (n_tx + tiles - 1) / tiles;
             const uint64_t items = (uint64_t)strips * rows_total;
             if (items > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
-            unsigned per_cu = 7;
-            if (const char *e_ = getenv("MARAY_JIT_BLOCKS_PER_CU")) if (atoi(e_) > 0) per_cu = (unsigned)atoi(e_);      // tuning knob
+            const unsigned per_cu = k_per_cu;
             const unsigned blocks = (unsigned)std::min<uint64_t>((items + 3) / 4, (uint64_t)n_cu * per_cu);
             unsigned shift = 0xFFFFFFFFu;
             for (unsigned k = 0; k < 31; k++) if (strips == (1u << k)) shift = k;
