@@ -105,7 +105,11 @@ extern "C" int maray_gen_to_image(const maray_scene *s, const maray_texture *tex
     int n_dev_avail = 0;
     maray_hip_device_count(&n_dev_avail);
     uint32_t n_dev = opts && opts->n_devices ? opts->n_devices : (uint32_t)(n_dev_avail > 0 ? n_dev_avail : 1);
-    if (n_dev_avail > 0 && n_dev > (uint32_t)n_dev_avail)
+    // MARAY_GEN_WRAP_DEVICES=1 (tests): worker d drives physical device d mod visible -- the whole multi-device machinery
+    // (a thread and a context per worker, one shared build, one registered raster written by every context) on a one-GPU box
+    const char *env_wrap = getenv("MARAY_GEN_WRAP_DEVICES");
+    const bool wrap = env_wrap && env_wrap[0] == '1' && n_dev_avail > 0;
+    if (n_dev_avail > 0 && n_dev > (uint32_t)n_dev_avail && !wrap)
         return fail_with(MARAY_E_NO_DEVICE, "asked for " + std::to_string(n_dev) + " devices, " + std::to_string(n_dev_avail) + " visible");
     if (n_dev > (h + 7) / 8) n_dev = (h + 7) / 8;
     // Row tiles: ~16 MiB of raster each (the DMA engine's rate; the first copy starts early), but at least four per
@@ -144,7 +148,7 @@ extern "C" int maray_gen_to_image(const maray_scene *s, const maray_texture *tex
     };
     auto worker = [&](uint32_t d) {
         maray_ctx *ctx = nullptr;
-        int r = maray_hip_ctx_create((int)d, &prog, tex, n_tex, &co, &ctx);
+        int r = maray_hip_ctx_create(wrap ? (int)(d % (uint32_t)n_dev_avail) : (int)d, &prog, tex, n_tex, &co, &ctx);
         if (!r && !share[d].empty())
             r = maray_hip_render_tiles(ctx, w, h, share[d].data(), (uint32_t)(share[d].size() / 2), rgb8, on_tile, &tu);
         const std::string msg = r ? maray_last_error() : "";      // this thread's message, re-raised on the calling thread

