@@ -139,6 +139,8 @@ struct Emitter {
     std::vector<uint8_t> ybool;                 // PIXEL in: per y value; ROW out (dry run): what each OUT wrote
     std::vector<uint8_t> out_is_bool;
     const GuardPlan *plan = nullptr;            // guard -> bit(s) (identity when null)
+    uint32_t gw_inline_max = 12;
+    bool gw_lanes = false;                      // > 12 guard words: lane i of mr_gt<j> holds word 64 j + i of the tile at hand
     int stage_first = -1;                       // ROW: >= 0: OUT k goes to LDS, ys[(k - stage_first) * 65 + lane] (jit_source_rows)
     std::string td = "double", tm = "mr_mask";  // types of a value / a boolean in the generated text ("mr_d" / "mr_m": four pixels per lane)
     std::vector<double> ktab_vals;
@@ -219,7 +221,19 @@ struct Emitter {
                 const uint32_t gref = MARAY_INS_A(ins);
                 const bool row_guard = pixel && MARAY_REF_KIND(gref) == MARAY_K_YVAL;
                 if (row_guard && ignore_row_guards) continue;      // legal: an evaluator may ignore any SKIP op
-                if (!row_guard && pixel && aux < min_region) continue;     // a wave-level region too short to pay for its test and branch
+                if (!row_guard && pixel && min_region) {                   // a wave-level region too cheap to pay for its test and branch
+                    // what the region's ops cost the vector unit, roughly in instructions: a gather, a libm body or a division
+                    // is not "an op" (a 20-op region around a texture lookup is worth its branch)
+                    uint32_t cost = 0;
+                    for (uint32_t j = i + 1; j <= end && cost < min_region; j++)
+                        switch (MARAY_INS_OP(ops[j])) {
+                        case MARAY_OP_NOP: case MARAY_OP_SKIPZ: case MARAY_OP_SKIPNZ: break;
+                        case MARAY_OP_RECIP: case MARAY_OP_SQRT: cost += 12; break;
+                        case MARAY_OP_SIN: case MARAY_OP_EXP: case MARAY_OP_LN: case MARAY_OP_STEPSIN: case MARAY_OP_APP: cost += 30; break;
+                        default: cost += 1;
+                        }
+                    if (cost < min_region) continue;
+                }
                 // the region's variable is a lane mask when its last op yields one: the guard tells for a wave-level
                 // region (a boolean guards a boolean AND / OR), the dry run for a row-level one (its guard is a y value)
                 const bool as_bool = row_guard ? (end < bool_hint.size() && bool_hint[end]) : va->kind == BOOL;
@@ -237,7 +251,13 @@ struct Emitter {
                 if (row_guard && !nz && guard_words && MARAY_REF_INDEX(gref) >= guard_first) {
                     // a row bound: one bit of a guard word that sits in an SGPR since the kernel's prologue
                     const uint32_t g = MARAY_REF_INDEX(gref) - guard_first;
-                    auto word = [&](uint32_t wi) { return guard_words <= 12 ? "gq" + std::to_string(wi) : "mr_uniform64(mr_gqt[" + std::to_string(wi) + "])"; };
+                    // a guard word: an SGPR pair by name (<= 12 words); beyond, lane wi % 64 of a per-lane value (one v_readlane
+                    // pair, the wave layout) or a word staged in LDS (the first layout)
+                    auto word = [&](uint32_t wi) {
+                        if (guard_words <= gw_inline_max) return "gq" + std::to_string(wi);
+                        if (gw_lanes) return "mr_lane64(mr_gt" + std::to_string(wi / 64) + ", " + std::to_string(wi % 64) + "u)";
+                        return "mr_uniform64(mr_gqt[" + std::to_string(wi) + "])";
+                    };
                     // tests on 32-bit halves of the words: s_and_b32 sets SCC and the branch follows (a 64-bit test is
                     // s_and + s_cmp_u64 + the branch, on the unit that bounds the busy tiles)
                     std::vector<uint64_t> m(guard_words, 0);
@@ -673,6 +693,14 @@ uint32_t jit_px()
     return (e_ && e_[0] == '1') ? 1u : 4u;
 }
 
+// Up to this many guard words a tile's words are named SGPR pairs (wave layout); beyond, they stay one per lane and a
+// test takes its word with v_readlane.  MARAY_JIT_GW_MANY=1 (tests): the second form whatever the count.
+uint32_t jit_gw_inline_max()
+{
+    const char *e_ = getenv("MARAY_JIT_GW_MANY");
+    return (e_ && e_[0] == '1') ? 0u : 12u;
+}
+
 // Which wavefronts take a tile where shapes may show: one wavefront in four passes of 64 pixels (default), or the block's
 // four side by side, one 64-pixel run each (MARAY_JIT_LAYOUT=coop: every wavefront then walks every tile of the strip,
 // and a strip of sky costs what it did with one pixel per lane: chess 48.5 against 44.4 us per frame, measured).
@@ -727,7 +755,8 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
     const uint32_t n_gwords = jit_guard_words(P);
     E.ignore_row_guards = n_gwords == 0;
     const GuardPlan plan = jit_guard_plan(P);
-    if (n_gwords) { E.guard_first = n_ynum; E.guard_words = n_gwords; E.plan = &plan; }
+    const uint32_t gw_max = jit_gw_inline_max();
+    if (n_gwords) { E.guard_first = n_ynum; E.guard_words = n_gwords; E.plan = &plan; E.gw_lanes = true; E.gw_inline_max = gw_max; }
     const bool defer = may_defer_tiles(P);
     const std::string nw = std::to_string(n_gwords);
     const bool coop = jit_coop();
@@ -735,7 +764,7 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
     // a strip's guard words: one vector load per wavefront (lane i holds word i), then v_readlane per tile -- one memory
     // latency per strip instead of one per tile (MARAY_JIT_GW=sload: scalar loads per tile; measurement knob)
     const char *env_gw = getenv("MARAY_JIT_GW");
-    const bool gw_vgpr = n_gwords && n_gwords <= 12 && !(env_gw && !strcmp(env_gw, "sload"));
+    const bool gw_vgpr = n_gwords && n_gwords <= gw_max && !(env_gw && !strcmp(env_gw, "sload"));
     // the general section four wide: only a short program whose ops are single instructions (no libm bodies, no gathers)
     bool heavy = false;
     for (uint32_t i = 0; i < P.n_pix_ops; i++) {
@@ -814,11 +843,13 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
         if (gw_vgpr)
             for (uint32_t j = 0; j < n_gwords; j++)
                 s += "    mr_mask gq" + std::to_string(j) + " = mr_lane64(mr_gv, t * " + nw + "u + " + std::to_string(j) + "u);\n";
-        else if (n_gwords <= 12)
+        else if (n_gwords <= gw_max)
             for (uint32_t j = 0; j < n_gwords; j++)
                 s += "    mr_mask gq" + std::to_string(j) + " = mr_gk[" + std::to_string(j) + "u];\n";
-        else
-            s += "    const mr_gptr mr_gqt = mr_gk;        // this tile's guard words, read where they are tested\n";
+        else        // many words: lane i of mr_gt<j> holds word 64 j + i of this tile (one vector load each); a test takes its word with v_readlane
+            for (uint32_t j = 0; j < (n_gwords + 63) / 64; j++)
+                s += "    unsigned long long mr_gt" + std::to_string(j) + " = " + std::to_string(64 * j) + "u + mr_lane < " + nw + "u ? ((const unsigned long long *)mr_gbase)[t * " + nw + "u + " +
+                     std::to_string(64 * j) + "u + mr_lane] : 0ull;\n";
     }
     if (defer) s += "    ((volatile unsigned *)mr_slow)[mr_wv] = 0u;\n    bool mr_slow_tile = false;\n";
     // a tile for one wavefront: the block's four take such tiles in turn
@@ -846,11 +877,14 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
     // the tile's guard words, opaque anew in every pass: left visible, all their bit tests are loop invariants too
     // (168 booleans for chess, hoisted and spilled to VGPR lanes)
     std::string gq_pass;
-    if (n_gwords && n_gwords <= 12)
+    if (n_gwords && n_gwords <= gw_max)
         for (uint32_t j = 0; j < n_gwords; j++) {
             const std::string k = std::to_string(j);
             gq_pass += "    asm volatile(\"\" : \"+s\"(gq" + k + "));\n";
         }
+    else if (n_gwords)
+        for (uint32_t j = 0; j < (n_gwords + 63) / 64; j++)
+            gq_pass += "    asm volatile(\"\" : \"+v\"(mr_gt" + std::to_string(j) + "));\n";
     const std::string wide_open =
         "    {\n" + opaque + gq_pass +
         "    const unsigned xa = x0 + mr_xl;                                        // this lane's first pixel\n"
@@ -911,14 +945,14 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
 
     if (n_gwords) {
         // the variant of a tile with no guard bit set, four pixels per lane
-        if (n_gwords <= 12) {
+        if (n_gwords <= gw_max) {
             std::string any = "gq0";
             for (uint32_t j = 1; j < n_gwords; j++) any += " | gq" + std::to_string(j);
             s += "    if ((" + any + ") == 0ull) {\n";
         } else {
-            s += "    mr_mask mr_any_g = 0ull;\n"
-                 "    for (unsigned i = 0; i < " + nw + "u; i++) mr_any_g |= mr_gqt[i];\n"
-                 "    if (mr_any_g == 0ull) {\n";
+            std::string any = "mr_gt0";
+            for (uint32_t j = 1; j < (n_gwords + 63) / 64; j++) any += " | mr_gt" + std::to_string(j);
+            s += "    if (mr_ballot((" + any + ") != 0ull) == 0ull) {\n";
         }
         E.td = "mr_d"; E.tm = "mr_m";
         E.assume_guards_zero = true;
@@ -1610,7 +1644,7 @@ struct JitBackend final : Backend {
             const bool coop = k_coop;
             tiles = coop ? 8 : 2;
             if (k_tiles) tiles = std::min(64u, k_tiles);
-            if (n_gwords && n_gwords <= 12) tiles = std::min(tiles, 64u / n_gwords);
+            if (n_gwords && n_gwords <= jit_gw_inline_max()) tiles = std::min(tiles, 64u / n_gwords);
             tiles = std::max(1u, std::min(tiles, n_tx));
             gx = coop ? (n_tx + tiles - 1) / tiles : (n_tx + 4 * tiles - 1) / (4 * tiles);
         } else {

@@ -469,6 +469,7 @@ def test_specialised_kernel_variants_selected_by_tuning_knobs(chess_bytes, monke
                 {'MARAY_JIT_YBOOL': '0'}, {'MARAY_JIT_ROW_OVERLAP': '1'}, {'MARAY_JIT_DERIVED': '0'}, {'MARAY_JIT_TILES': '1'}, {'MARAY_JIT_TILES': '5', 'MARAY_JIT_ROW_BLOCK': '64'},
                 {'MARAY_JIT_ROW_GUARDS': '0'}, {'MARAY_JIT_KTAB': '0'}, {'MARAY_JIT_NO_ORDER': '1'}, {'MARAY_JIT_ROW_CHUNK_OPS': '300'},
                 {'MARAY_JIT_PERSIST': '1'}, {'MARAY_JIT_PERSIST': '1', 'MARAY_JIT_TILES': '3', 'MARAY_JIT_BLOCKS_PER_CU': '2'},
+                {'MARAY_JIT_GW_MANY': '1'}, {'MARAY_JIT_GW_MANY': '1', 'MARAY_JIT_TILES': '5'},
                 px1, dict(px1, MARAY_JIT_YLDS='1'), dict(px1, MARAY_JIT_ROW_GUARDS='0'), dict(px1, MARAY_JIT_TILES='1'), dict(px1, MARAY_JIT_KTAB='0'),
                 dict(px1, MARAY_JIT_ROW_BLOCK='64', MARAY_JIT_TILES='3'), dict(px1, MARAY_JIT_GLDS='0'), dict(px1, MARAY_JIT_ROWS_REVERSED='1')):
         for k, v in env.items():
