@@ -1580,7 +1580,8 @@ struct JitBackend final : Backend {
         const int b = rows_pass ? (cur_set ^ 1) : cur_set;
         hipStream_t rs = overlap ? row_stream : st;
         if (rows_pass) {
-            if (pix_done_set[b]) HIP_TRY(hipStreamWaitEvent(rs, pix_done[b], 0));       // the reader of this set has finished
+            // (one stream: launches are ordered already, and an event wait between them costs a signal round trip: 5.7 us per frame)
+            if (overlap && pix_done_set[b]) HIP_TRY(hipStreamWaitEvent(rs, pix_done[b], 0));       // the reader of this set has finished
             ensure(d_yvals2[b], yvals_cap2[b], (size_t)rows_total * std::max<uint32_t>(P.n_yvals, 1));
             const size_t had = gbits_cap2[b];
             ensure(d_gbits2[b], gbits_cap2[b], (size_t)n_groups * ((w + 255) / 256) * std::max<uint32_t>(n_gwords, 1));
@@ -1618,7 +1619,7 @@ struct JitBackend final : Backend {
             if (!cached && rows_pass && again) {
                 order_key[0] = order_key[1] = order_key[2] = 0;     // no geometry owns d_order until the kernel below is enqueued
                 // an earlier launch (another geometry) may still be reading the table: its pixel kernel first
-                if (pix_done_set[b ^ 1]) HIP_TRY(hipStreamWaitEvent(rs, pix_done[b ^ 1], 0));
+                if (overlap && pix_done_set[b ^ 1]) HIP_TRY(hipStreamWaitEvent(rs, pix_done[b ^ 1], 0));
                 ensure(d_order, order_cap, (size_t)rows_total);
                 unsigned rr = rows_total, n_tx_ = (w + 255) / 256;
                 void *oargs[] = {&d_gbits, &d_order, &rr, &n_tx_, &yrows};
@@ -1684,8 +1685,10 @@ struct JitBackend final : Backend {
             HIP_TRY(hipModuleLaunchKernel(f_pix, gx, rows, 1, 256, 1, 1, 0, st, args, nullptr));
         }
         if (has_sin) slow->render_flagged(w, rb, d8, d64, st, d_flags, d_yvals);   // no-op unless a tile was deferred
-        HIP_TRY(hipEventRecord(pix_done[b], st));
-        pix_done_set[b] = true;
+        if (overlap) {
+            HIP_TRY(hipEventRecord(pix_done[b], st));
+            pix_done_set[b] = true;
+        }
     }
 
     void render_device(uint32_t w, uint32_t, const RowBlocks &rb, void *d8, void *d64, void *stream) override {
