@@ -558,6 +558,13 @@ uint32_t jit_guard_rows(const maray_program &P)
     return (jit_guard_words(P) && !any_guard_reads_y(P)) ? 8u : 1u;
 }
 
+// Threads per block of the ROW kernel (MARAY_JIT_ROW_BLOCK: 64 .. 1024, tuning knob; part of the generated source).
+unsigned jit_row_block()
+{
+    if (const char *e_ = getenv("MARAY_JIT_ROW_BLOCK")) if (atoi(e_) >= 64 && atoi(e_) <= 1024 && atoi(e_) % 64 == 0) return (unsigned)atoi(e_);
+    return 256;
+}
+
 // Source of the ROW kernel, maray_jit_rows: one wavefront per block, blockIdx.y picks the job.
 //  y < n_chunks: chunk y of the ROW section, one work-item per row; writes the y values the pixel
 //    kernel reads as operands (and, for a program that may defer tiles to the interpreter, the
@@ -588,7 +595,8 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
          std::to_string(chunks.size()) + " chunks, " + std::to_string(P.n_yvals - n_ynum) + " guards in " + std::to_string(n_gwords) + " words\n";
     s += "#include \"device_math.h\"\n\n";
     const char *env_rw = getenv("MARAY_JIT_ROW_WAVES");          // tuning knob: occupancy hint of the ROW kernel
-    s += "extern \"C\" __global__ void __launch_bounds__(256" + (env_rw ? ", " + std::string(env_rw) : std::string()) + ") maray_jit_rows(double *__restrict__ yvals, unsigned long long *__restrict__ gbits,\n"
+    const unsigned row_block = jit_row_block();
+    s += "extern \"C\" __global__ void __launch_bounds__(" + std::to_string(row_block) + (env_rw ? ", " + std::string(env_rw) : std::string()) + ") maray_jit_rows(double *__restrict__ yvals, unsigned long long *__restrict__ gbits,\n"
          "                                                                 const MarayTex *__restrict__ tex,\n"
          "                                                                 unsigned y0, unsigned rows, unsigned n_yvals, unsigned w, unsigned n_tx,\n"
          "                                                                 unsigned blk_rows, unsigned blk_stride, unsigned yrows)\n{\n"
@@ -600,7 +608,7 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
          "    // way) and leave as rows of the table, a chunk's values side by side: full cache lines.  Stored from the registers, a\n"
          "    // wavefront's store touches 64 lines for 8 bytes each -- 1.2 M partial writes per frame, which is what the kernel\n"
          "    // then waits for (11.8 us; the arithmetic needs 2).\n"
-         "    __shared__ double mr_ys[4 * " + std::to_string(ROW_CHUNK_MAX_OUTS * 65) + "];\n"
+         "    __shared__ double mr_ys[" + std::to_string(row_block / 64) + " * " + std::to_string(ROW_CHUNK_MAX_OUTS * 65) + "];\n"
          "    const unsigned mr_lane = threadIdx.x & 63u;\n"
          "    double *ys = mr_ys + (threadIdx.x >> 6) * " + std::to_string(ROW_CHUNK_MAX_OUTS * 65) + "u;\n"
          "    const unsigned long long row0 = item - mr_lane;                       // first row of this wavefront\n"
@@ -1508,7 +1516,7 @@ struct JitBackend final : Backend {
         px = jit_px();
         k_coop = jit_coop(); k_persist = jit_persist();
         if (const char *e_ = getenv("MARAY_JIT_ROW_OVERLAP")) k_overlap = e_[0] == '1';
-        if (const char *e_ = getenv("MARAY_JIT_ROW_BLOCK")) if (atoi(e_) >= 64 && atoi(e_) <= 256 && atoi(e_) % 64 == 0) k_row_block = (unsigned)atoi(e_);
+        k_row_block = jit_row_block();
         if (const char *e_ = getenv("MARAY_JIT_ROW_PART")) k_rows_chunks_only = e_[0] == '1';       // measurement: y-value jobs only (wrong pixels!)
         if (const char *e_ = getenv("MARAY_JIT_TILES")) if (atoi(e_) > 0) k_tiles = (unsigned)atoi(e_);
         if (const char *e_ = getenv("MARAY_JIT_BLOCKS_PER_CU")) if (atoi(e_) > 0) k_per_cu = (unsigned)atoi(e_);
