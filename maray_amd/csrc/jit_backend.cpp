@@ -602,7 +602,9 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
          "                                                                 unsigned blk_rows, unsigned blk_stride, unsigned yrows)\n{\n"
          "    const unsigned long long item = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;\n"
          "    (void)tex; (void)gbits; (void)n_tx;\n"
-         "    if (blockIdx.y < " + std::to_string(chunks.size()) + "u) {\n"
+         "    // guard jobs first in the grid (they are the long ones: the y-value jobs fill in behind them): job = the switch index\n"
+         "    const unsigned mr_job = blockIdx.y < " + std::to_string(n_gjobs) + "u ? " + std::to_string(chunks.size()) + "u + blockIdx.y : blockIdx.y - " + std::to_string(n_gjobs) + "u;\n"
+         "    if (mr_job < " + std::to_string(chunks.size()) + "u) {\n"
          + std::string(getenv("MARAY_JIT_ROW_PART") && getenv("MARAY_JIT_ROW_PART")[0] == '2' ? "    return;      // measurement: guard jobs only (wrong pixels!)\n" : "") +
          "    // y values: a work-item per row.  A lane's values go to LDS ([value][row], values 65 apart: no bank conflicts either\n"
          "    // way) and leave as rows of the table, a chunk's values side by side: full cache lines.  Stored from the registers, a\n"
@@ -618,7 +620,7 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
          "    const double YMIN = Y, YMAX = Y;\n"
          "    (void)Y; (void)XMIN; (void)XMAX; (void)YMIN; (void)YMAX; (void)yrows;\n"
          "    unsigned mr_k0 = 0u, mr_kn = 0u;\n"
-         "    switch (blockIdx.y) {\n";
+         "    switch (mr_job) {\n";
     for (size_t k = 0; k < chunks.size(); k++) {
         s += "    case " + std::to_string(k) + ": {\n";
         E.stage_first = (int)rc.first[k];
@@ -634,6 +636,7 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
          "    }\n"
          "    return;\n    }\n";
     if (n_gwords) {
+        if (getenv("MARAY_JIT_ROW_PART") && getenv("MARAY_JIT_ROW_PART")[0] == '1') s += "    return;      // measurement: y-value jobs only (wrong pixels!)\n";
         s += "    // guards: (row group, tile), the tiles of a group adjacent\n"
              "    const unsigned n_groups = (rows + yrows - 1u) / yrows;\n"
              "    if (item >= (unsigned long long)n_groups * n_tx) return;\n"
@@ -646,7 +649,7 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
              "    unsigned long long gacc = 0ull;\n"
              "    double *yout = nullptr;\n"
              "    (void)Y; (void)XMIN; (void)XMAX; (void)YMIN; (void)YMAX; (void)yout;\n"
-             "    switch (blockIdx.y - " + std::to_string(chunks.size()) + "u) {\n";
+             "    switch (mr_job - " + std::to_string(chunks.size()) + "u) {\n";
         E.out_guard_bits = true;
         E.guard_first = n_ynum;
         E.plan = &plan;
@@ -664,7 +667,7 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
             s += "    } break;\n";
         }
         s += "    }\n"
-             "    ((unsigned char *)gbits)[item * " + std::to_string(8 * n_gwords) + "u + (blockIdx.y - " + std::to_string(chunks.size()) + "u)] = (unsigned char)gacc;\n";
+             "    ((unsigned char *)gbits)[item * " + std::to_string(8 * n_gwords) + "u + (mr_job - " + std::to_string(chunks.size()) + "u)] = (unsigned char)gacc;\n";
     }
     s += "}\n";
     // Launch order of the PIXEL kernel: groups of rows by what they cost, dearest first, so that the tail of the launch is
@@ -1479,7 +1482,7 @@ struct JitBackend final : Backend {
     uint32_t n_row_chunks = 1, n_gwords = 0, n_gjobs = 0, guard_rows = 1;
     uint32_t n_cu = 256;
     // launch-time tuning knobs, read once when the context is created
-    bool k_overlap = false, k_coop = false, k_persist = false, k_rows_chunks_only = false;
+    bool k_overlap = false, k_coop = false, k_persist = false;
     unsigned k_row_block = 256, k_tiles = 0, k_per_cu = 7;
     uint32_t px = 4;                    // pixels per lane of the PIXEL kernel this context was built with
     bool has_sin = false;               // some Sin argument is not proven bounded: tiles may be deferred to `slow`
@@ -1517,7 +1520,6 @@ struct JitBackend final : Backend {
         k_coop = jit_coop(); k_persist = jit_persist();
         if (const char *e_ = getenv("MARAY_JIT_ROW_OVERLAP")) k_overlap = e_[0] == '1';
         k_row_block = jit_row_block();
-        if (const char *e_ = getenv("MARAY_JIT_ROW_PART")) k_rows_chunks_only = e_[0] == '1';       // measurement: y-value jobs only (wrong pixels!)
         if (const char *e_ = getenv("MARAY_JIT_TILES")) if (atoi(e_) > 0) k_tiles = (unsigned)atoi(e_);
         if (const char *e_ = getenv("MARAY_JIT_BLOCKS_PER_CU")) if (atoi(e_) > 0) k_per_cu = (unsigned)atoi(e_);
         code = jit_code_for(prog);                       // built by the first context of the process, or read from the cache
@@ -1610,7 +1612,6 @@ struct JitBackend final : Backend {
             if ((items + bs - 1) / bs > 0x7FFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
             void *args[] = {&d_yvals, &d_gbits, &d_tex, &yy0, &rr, &n_yvals, &ww, &n_tx_, &blk_rows, &blk_stride, &yrows};
             unsigned gy = n_row_chunks + n_gjobs;
-            if (k_rows_chunks_only) gy = n_row_chunks;
             HIP_TRY(hipModuleLaunchKernel(f_rows, (unsigned)((items + bs - 1) / bs), gy, 1, bs, 1, 1, 0, rs, args, nullptr));
         }
         // launch order of the PIXEL kernel (maray_jit_order): once per geometry, from the guard bits the ROW kernel just wrote;
