@@ -712,6 +712,19 @@ uint32_t jit_gw_inline_max()
     return (e_ && e_[0] == '1') ? 0u : 12u;
 }
 
+// The general section four pixels per lane: only a short program without guards whose ops are single instructions (no libm
+// bodies, no gathers).  MARAY_JIT_WIDE=0/1: never / always (measurement knob).
+bool jit_wide_general(const maray_program &P)
+{
+    if (const char *e_ = getenv("MARAY_JIT_WIDE")) return e_[0] == '1';
+    bool heavy = false;
+    for (uint32_t i = 0; i < P.n_pix_ops; i++) {
+        const uint32_t op = MARAY_INS_OP(P.pix_ops[i]);
+        heavy |= op == MARAY_OP_SIN || op == MARAY_OP_EXP || op == MARAY_OP_LN || op == MARAY_OP_STEPSIN || op == MARAY_OP_APP;
+    }
+    return jit_guard_words(P) == 0 && !heavy && P.n_pix_slots <= 6 && P.n_pix_ops <= 256;
+}
+
 // Which wavefronts take a tile where shapes may show: one wavefront in four passes of 64 pixels (default), or the block's
 // four side by side, one 64-pixel run each (MARAY_JIT_LAYOUT=coop: every wavefront then walks every tile of the strip,
 // and a strip of sky costs what it did with one pixel per lane: chess 48.5 against 44.4 us per frame, measured).
@@ -776,14 +789,7 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
     // latency per strip instead of one per tile (MARAY_JIT_GW=sload: scalar loads per tile; measurement knob)
     const char *env_gw = getenv("MARAY_JIT_GW");
     const bool gw_vgpr = n_gwords && n_gwords <= gw_max && !(env_gw && !strcmp(env_gw, "sload"));
-    // the general section four wide: only a short program whose ops are single instructions (no libm bodies, no gathers)
-    bool heavy = false;
-    for (uint32_t i = 0; i < P.n_pix_ops; i++) {
-        const uint32_t op = MARAY_INS_OP(P.pix_ops[i]);
-        heavy |= op == MARAY_OP_SIN || op == MARAY_OP_EXP || op == MARAY_OP_LN || op == MARAY_OP_STEPSIN || op == MARAY_OP_APP;
-    }
-    bool wide_general = n_gwords == 0 && !heavy && P.n_pix_slots <= 6 && P.n_pix_ops <= 256;
-    if (const char *e_ = getenv("MARAY_JIT_WIDE")) wide_general = e_[0] == '1';            // measurement knob
+    const bool wide_general = jit_wide_general(P);
     s += "// generated by libmaray_hip (jit_backend.cpp) from a v" + std::to_string(P.version) + " tape: PIXEL section, " +
          std::to_string(P.n_pix_ops) + " ops; general variant " + (wide_general ? "four pixels per lane, a wavefront per tile" : "one pixel per lane, four wavefronts per tile") + "\n"
          "#define MR_VEC4 1\n"
@@ -1482,7 +1488,7 @@ struct JitBackend final : Backend {
     uint32_t n_row_chunks = 1, n_gwords = 0, n_gjobs = 0, guard_rows = 1;
     uint32_t n_cu = 256;
     // launch-time tuning knobs, read once when the context is created
-    bool k_overlap = false, k_coop = false, k_persist = false;
+    bool k_overlap = false, k_coop = false, k_persist = false, wide_all = false;
     unsigned k_row_block = 256, k_tiles = 0, k_per_cu = 7;
     uint32_t px = 4;                    // pixels per lane of the PIXEL kernel this context was built with
     bool has_sin = false;               // some Sin argument is not proven bounded: tiles may be deferred to `slow`
@@ -1518,6 +1524,7 @@ struct JitBackend final : Backend {
         has_sin = may_defer_tiles(prog);
         px = jit_px();
         k_coop = jit_coop(); k_persist = jit_persist();
+        wide_all = jit_wide_general(prog);
         if (const char *e_ = getenv("MARAY_JIT_ROW_OVERLAP")) k_overlap = e_[0] == '1';
         k_row_block = jit_row_block();
         if (const char *e_ = getenv("MARAY_JIT_TILES")) if (atoi(e_) > 0) k_tiles = (unsigned)atoi(e_);
@@ -1651,8 +1658,10 @@ struct JitBackend final : Backend {
         if (px == 4) {
             // a block (or, MARAY_JIT_LAYOUT=wave, a wavefront) owns `tiles` consecutive tiles of a row; a strip's guard
             // words are one word per lane of a wavefront
+            // (every tile of a program without guards costs the same: long strips, nothing to balance -- config 2 at 8192^2:
+            // 2.74 -> 2.88 TB/s with 8 tiles; only for the cheap four-wide sections, a narrow wavefront would live too long)
             const bool coop = k_coop;
-            tiles = coop ? 8 : 2;
+            tiles = coop || wide_all ? 8 : 2;
             if (k_tiles) tiles = std::min(64u, k_tiles);
             if (n_gwords && n_gwords <= jit_gw_inline_max()) tiles = std::min(tiles, 64u / n_gwords);
             tiles = std::max(1u, std::min(tiles, n_tx));

@@ -50,6 +50,24 @@ def test_radial_gradient_1024_bit_exact():
     gpu_vs_oracle(data, 1024, 1024, [(0, 32), (1000, 1024)])
 
 
+def test_radial_gradient_8192_rgb8_whole_image():
+    """Config 2 at the size its throughput is quoted on (8192^2, 192 MiB of RGB8): the whole raster against
+    min(255, floor(sqrt(x^2 + y^2))) -- x^2 + y^2 < 2^27 is exact in f64 and sqrt is correctly rounded, so this holds
+    unconditionally; ragged row ranges through the pipelined host path."""
+    data = encode((8192, 8192), scenes.radial_gradient())
+    ctx = M.Context(M.Scene(data).lower(), backend=M.BACKEND_JIT)
+    got8, _ = ctx.render_rows(8192, 8192, 0, 8192, want_f64=False)
+    part8, _ = ctx.render_rows(8192, 8192, 4093, 4099, want_f64=False)
+    ctx.close()
+    xx = np.arange(8192, dtype=np.float64)
+    for y0 in range(0, 8192, 1024):                                  # in bands: the f64 reference would be 1.6 GB at once
+        yy = np.arange(y0, y0 + 1024, dtype=np.float64)[:, None]
+        want = np.minimum(np.floor(np.sqrt(xx * xx + yy * yy)), 255).astype(np.uint8)
+        assert np.array_equal(got8[y0:y0 + 1024, :, 0], want), y0
+        assert np.array_equal(got8[y0:y0 + 1024, :, 1], want) and np.array_equal(got8[y0:y0 + 1024, :, 2], want)
+    assert np.array_equal(part8, got8[4093:4099])
+
+
 def test_chess_1024_full_raster_matches_golden(chess_bytes):
     """Config 1 on the GPU: full 1024^2 raster equals the oracle's committed hash,
     and the PNG fixture to >= 99.98 % with mismatches only on rows 512 / 704."""
