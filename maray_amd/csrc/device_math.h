@@ -159,4 +159,44 @@ MARAY_DEV mr_d mr_app(const MarayTex *tex, unsigned id, const mr_d &x, const mr_
 {
     return mr_d(mr_app(tex, id, x.a, y.a), mr_app(tex, id, x.b, y.b), mr_app(tex, id, x.c, y.c), mr_app(tex, id, x.d, y.d));
 }
+
+// ---- two pixels per lane (MARAY_JIT_NARROW=2: the busy-tile variant in two passes of 128 pixels) ------------------
+struct mr_d2 {
+    double a, b;
+    MARAY_DEV mr_d2() {}
+    MARAY_DEV mr_d2(double s) : a(s), b(s) {}
+    MARAY_DEV mr_d2(double a_, double b_) : a(a_), b(b_) {}
+};
+struct mr_m2 {
+    mr_mask a, b;
+    MARAY_DEV mr_m2() {}
+    MARAY_DEV mr_m2(mr_mask s) : a(s), b(s) {}
+    MARAY_DEV mr_m2(mr_mask a_, mr_mask b_) : a(a_), b(b_) {}
+};
+#define MR_EACH2(f, v) mr_d2(f((v).a), f((v).b))
+MARAY_DEV mr_d2 operator+(const mr_d2 &x, const mr_d2 &y) { return mr_d2(x.a + y.a, x.b + y.b); }
+MARAY_DEV mr_d2 operator*(const mr_d2 &x, const mr_d2 &y) { return mr_d2(x.a * y.a, x.b * y.b); }
+MARAY_DEV mr_m2 operator&(const mr_m2 &x, const mr_m2 &y) { return mr_m2(x.a & y.a, x.b & y.b); }
+MARAY_DEV mr_m2 operator|(const mr_m2 &x, const mr_m2 &y) { return mr_m2(x.a | y.a, x.b | y.b); }
+MARAY_DEV mr_m2 operator~(const mr_m2 &x) { return mr_m2(~x.a, ~x.b); }
+MARAY_DEV bool mr_any(const mr_m2 &m) { return (m.a | m.b) != MR_NONE; }
+MARAY_DEV mr_d2 mr_pos(const mr_m2 &m) { return mr_d2(mr_pos(m.a), mr_pos(m.b)); }
+MARAY_DEV mr_d2 mr_neg01(const mr_m2 &m) { return mr_d2(mr_neg01(m.a), mr_neg01(m.b)); }
+MARAY_DEV mr_m2 mr_ge0(const mr_d2 &v) { return mr_m2(mr_ge0(v.a), mr_ge0(v.b)); }
+MARAY_DEV mr_m2 mr_ne0(const mr_d2 &v) { return mr_m2(mr_ne0(v.a), mr_ne0(v.b)); }
+MARAY_DEV mr_m2 mr_ne1(const mr_d2 &v) { return mr_m2(mr_ne1(v.a), mr_ne1(v.b)); }
+MARAY_DEV mr_m2 mr_stepsin_bounded_m(const mr_d2 &v) { return mr_m2(mr_stepsin_bounded_m(v.a), mr_stepsin_bounded_m(v.b)); }
+MARAY_DEV mr_d2 mr_neg(const mr_d2 &v) { return MR_EACH2(mr_neg, v); }
+MARAY_DEV mr_d2 mr_abs(const mr_d2 &v) { return MR_EACH2(mr_abs, v); }
+MARAY_DEV mr_d2 mr_recip(const mr_d2 &v) { return MR_EACH2(mr_recip, v); }
+MARAY_DEV mr_d2 mr_sqrt(const mr_d2 &v) { return MR_EACH2(mr_sqrt, v); }
+MARAY_DEV mr_d2 mr_sin(const mr_d2 &v) { return MR_EACH2(mr_sin, v); }
+MARAY_DEV mr_d2 mr_sin_bounded(const mr_d2 &v) { return MR_EACH2(mr_sin_bounded, v); }
+MARAY_DEV mr_d2 mr_exp(const mr_d2 &v) { return MR_EACH2(mr_exp, v); }
+MARAY_DEV mr_d2 mr_ln(const mr_d2 &v) { return MR_EACH2(mr_ln, v); }
+MARAY_DEV mr_d2 mr_stepsin(const mr_d2 &v) { return MR_EACH2(mr_stepsin, v); }
+MARAY_DEV mr_d2 mr_stepsin_fast(const mr_d2 &v, float *defer) { return mr_d2(mr_stepsin_fast(v.a, defer), mr_stepsin_fast(v.b, defer)); }
+MARAY_DEV mr_d2 mr_max(const mr_d2 &x, const mr_d2 &y) { return mr_d2(mr_max(x.a, y.a), mr_max(x.b, y.b)); }
+MARAY_DEV mr_d2 mr_min(const mr_d2 &x, const mr_d2 &y) { return mr_d2(mr_min(x.a, y.a), mr_min(x.b, y.b)); }
+MARAY_DEV mr_d2 mr_app(const MarayTex *tex, unsigned id, const mr_d2 &x, const mr_d2 &y) { return mr_d2(mr_app(tex, id, x.a, y.a), mr_app(tex, id, x.b, y.b)); }
 #endif

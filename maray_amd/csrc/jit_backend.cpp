@@ -1000,22 +1000,43 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
                  "    }\n" + tile_end;
         } else {
             // one wavefront, four passes of 64 pixels (a loop, not unrolled); the passes leave their packed pixels in LDS
-            // (same-wave traffic: no barrier) and a whole aligned tile is stored as a dwordx3 per lane
+            // (same-wave traffic: no barrier) and a whole aligned tile is stored as a dwordx3 per lane.
+            // MARAY_JIT_NARROW=2: two passes of 128 pixels, two pixels per lane (measurement knob).
+            const char *env_nw = getenv("MARAY_JIT_NARROW");
+            const bool two = env_nw && env_nw[0] == '2';
+            if (two) { E.td = "mr_d2"; E.tm = "mr_m2"; }
             s += "    const bool mr_fast = rgb8 && x0 + 256u <= w && ((size_t)(rgb8 + (row_px + x0) * 3) & 3u) == 0u;      // wave-uniform\n"
-                 "    _Pragma(\"unroll 1\") for (unsigned e = 0; e < 4u; e++) {\n" + opaque + gq_pass +
-                 "    const unsigned xw = x0 + 64u * e, x = xw + mr_lane;\n"
-                 "    const double X = (double)x;\n"
-                 "    double o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"
+                 "    _Pragma(\"unroll 1\") for (unsigned e = 0; e < " + std::string(two ? "2u" : "4u") + "; e++) {\n" + opaque + gq_pass +
+                 (two ? "    const unsigned xw = x0 + 128u * e, x = xw + mr_lane;\n"
+                        "    const mr_d2 X((double)x, (double)(x + 64u));\n"
+                        "    mr_d2 o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"
+                      : "    const unsigned xw = x0 + 64u * e, x = xw + mr_lane;\n"
+                        "    const double X = (double)x;\n"
+                        "    double o0 = 0.0, o1 = 0.0, o2 = 0.0;\n") +
                  "    float mr_defer = 0.0f;\n"
                  "    (void)X; (void)mr_defer;\n";
             E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
-            s += defer_pass +
-                 "    const unsigned pk = mr_cast_u8(o0) | (mr_cast_u8(o1) << 8) | (mr_cast_u8(o2) << 16);\n"
-                 "    if (mr_fast) {\n"
-                 "        mr_tp[mr_wv * 256u + 64u * e + mr_lane] = pk;\n"
-                 "        mr_store_run(nullptr, rgb64, row_px, xw, w, mr_lane, mr_src, mr_shift, pk, o0, o1, o2);\n"
-                 "    } else mr_store_run(rgb8, rgb64, row_px, xw, w, mr_lane, mr_src, mr_shift, pk, o0, o1, o2);\n"
-                 "    }\n"
+            E.td = "double"; E.tm = "mr_mask";
+            s += defer_pass;
+            if (two)
+                s += "    const unsigned pka = mr_cast_u8(o0.a) | (mr_cast_u8(o1.a) << 8) | (mr_cast_u8(o2.a) << 16);\n"
+                     "    const unsigned pkb = mr_cast_u8(o0.b) | (mr_cast_u8(o1.b) << 8) | (mr_cast_u8(o2.b) << 16);\n"
+                     "    if (mr_fast) {\n"
+                     "        mr_tp[mr_wv * 256u + 128u * e + mr_lane] = pka;\n"
+                     "        mr_tp[mr_wv * 256u + 128u * e + 64u + mr_lane] = pkb;\n"
+                     "        mr_store_run(nullptr, rgb64, row_px, xw, w, mr_lane, mr_src, mr_shift, pka, o0.a, o1.a, o2.a);\n"
+                     "        mr_store_run(nullptr, rgb64, row_px, xw + 64u, w, mr_lane, mr_src, mr_shift, pkb, o0.b, o1.b, o2.b);\n"
+                     "    } else {\n"
+                     "        mr_store_run(rgb8, rgb64, row_px, xw, w, mr_lane, mr_src, mr_shift, pka, o0.a, o1.a, o2.a);\n"
+                     "        mr_store_run(rgb8, rgb64, row_px, xw + 64u, w, mr_lane, mr_src, mr_shift, pkb, o0.b, o1.b, o2.b);\n"
+                     "    }\n";
+            else
+                s += "    const unsigned pk = mr_cast_u8(o0) | (mr_cast_u8(o1) << 8) | (mr_cast_u8(o2) << 16);\n"
+                     "    if (mr_fast) {\n"
+                     "        mr_tp[mr_wv * 256u + 64u * e + mr_lane] = pk;\n"
+                     "        mr_store_run(nullptr, rgb64, row_px, xw, w, mr_lane, mr_src, mr_shift, pk, o0, o1, o2);\n"
+                     "    } else mr_store_run(rgb8, rgb64, row_px, xw, w, mr_lane, mr_src, mr_shift, pk, o0, o1, o2);\n";
+            s += "    }\n"
                  "    if (mr_fast) {\n"
                  "        __builtin_amdgcn_wave_barrier();                                     // same wavefront wrote them: LDS keeps its order\n"
                  "        const mr_u4 p = *(const mr_u4 *)&mr_tp[mr_wv * 256u + 4u * mr_lane];\n"

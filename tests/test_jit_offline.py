@@ -72,9 +72,9 @@ def test_row_section_is_cut_into_chunks(chess_bytes):
     n_guards = tape.info['n_yvals'] - n_num
     # guards that are the OR of other guards (a group of shapes) have no job; the others, 8 bits = one byte per job
     n_bits = len(re.findall(r'gacc \|= ', guards_src))
-    assert 0 < n_bits < n_guards and n_bits >= 128 and 'ys[' not in guards_src.split('switch')[1]
+    assert 0 < n_bits < n_guards and n_bits >= 128 and 'ys[' not in guards_src.split('switch (')[1]
     assert guards_src.count('    case ') == (n_bits + 7) // 8
-    assert 'XMIN' in guards_src and 'XMIN' not in rows_src.split('switch')[1]      # only guards depend on the span
+    assert 'XMIN' in guards_src and 'XMIN' not in rows_src.split('switch (')[1]      # only guards depend on the span
     build(tape)        # compiles the ROW kernel as well
 
 
