@@ -102,6 +102,8 @@ std::string lit(double v)
 // is "any of its members' bits", one s_and on the word.  Computed in the ROW kernel such a guard costs its members'
 // cones all over again (chess: 40 group guards = 54 % of the ROW kernel's work, and the dearest jobs: 2,300 ops in a
 // chain where a shape's guard has 100-200).
+struct GuardGeom { uint32_t gw, gh; };          // the rectangle a guard is bounded over: gw pixels x gh rows (jit_guard_geom)
+
 struct GuardPlan {
     uint32_t n_pos = 0;                          // bits in use
     std::vector<int32_t> pos;                    // per guard: its bit, or -1: derived
@@ -551,12 +553,40 @@ uint32_t jit_guard_words(const maray_program &P)
     return nw <= 1024 ? std::max(nw, 1u) : 0;       // 1024 words x 8 tiles = 64 KB of LDS
 }
 
-// Rows per guard evaluation: 8 when no guard's cone reads Y (every guard then bounds its boolean over the rows
-// [YMIN, YMAX] too, include/maray_tape.h), else 1.
-uint32_t jit_guard_rows(const maray_program &P)
+uint32_t jit_px();
+uint32_t jit_gw_inline_max();
+bool jit_coop();
+bool jit_persist();
+
+// The rectangle a guard is bounded over: `gh` rows x `gw` pixels.  gh = 1 (and gw = 256) when some guard's cone reads Y;
+// else every guard bounds its boolean over the rows [YMIN, YMAX] too (include/maray_tape.h) and the rectangle is the
+// back-end's choice.  The number of rectangles is what the ROW kernel pays for, their shape is what the PIXEL kernel
+// gains from: a shape's edge is met by ~(extent / side + 1) rectangles each way, a wavefront enters regions per 64
+// pixels of ONE row, and shapes are tall against 8 rows -- so a rectangle that is narrower and taller by the same factor
+// costs the ROW kernel nothing and spares the PIXEL kernel region entries.  Default 64 x 32 (chess @4096^2, frame / board
+// crop in us, 256 x 8: 49.3 / 104; 256 x 16: 48.9 / 104; 128 x 16: 45.1 / 92; 64 x 8: 49.0 / 83 -- four times the guard work;
+// 64 x 16: 45.5 / 84; 64 x 32: 43.8 / 84; 64 x 64: 45.1 / 86; 64 x 128: 48.1 / 88).  MARAY_JIT_GUARD_W = 64 / 128 / 256,
+// MARAY_JIT_GUARD_H = 8 ... 128: measurement knobs.  Narrow rectangles only in the default PIXEL layout with the
+// strip's words held one per lane.
+GuardGeom jit_guard_geom(const maray_program &P)
 {
-    return (jit_guard_words(P) && !any_guard_reads_y(P)) ? 8u : 1u;
+    GuardGeom g{256u, 1u};
+    const uint32_t nw = jit_guard_words(P);
+    if (!nw || any_guard_reads_y(P)) return g;
+    g.gh = 32u;
+    if (const char *e_ = getenv("MARAY_JIT_GUARD_H")) { const int v = atoi(e_); if (v == 8 || v == 16 || v == 32 || v == 64 || v == 128) g.gh = (uint32_t)v; }
+    const char *env_gw = getenv("MARAY_JIT_GW");
+    const char *env_wide = getenv("MARAY_JIT_WIDE");       // (the whole section four pixels per lane tests a tile's bits once)
+    const bool lanes = jit_px() == 4 && !jit_coop() && !jit_persist() && nw <= jit_gw_inline_max() && !(env_gw && !strcmp(env_gw, "sload")) &&
+                       !(env_wide && env_wide[0] == '1');
+    uint32_t want = 64u;
+    if (const char *e_ = getenv("MARAY_JIT_GUARD_W")) { const int v = atoi(e_); if (v == 64 || v == 128 || v == 256) want = (uint32_t)v; }
+    while (want < 256u && !(lanes && nw * (256u / want) <= 64u)) want *= 2u;       // the words of one tile at least must fit a wavefront's lanes
+    g.gw = want;
+    return g;
 }
+
+uint32_t jit_guard_rows(const maray_program &P) { return jit_guard_geom(P).gh; }
 
 // Threads per block of the ROW kernel (MARAY_JIT_ROW_BLOCK: 64 .. 1024, tuning knob; part of the generated source).
 unsigned jit_row_block()
@@ -569,9 +599,9 @@ unsigned jit_row_block()
 //  y < n_chunks: chunk y of the ROW section, one work-item per row; writes the y values the pixel
 //    kernel reads as operands (and, for a program that may defer tiles to the interpreter, the
 //    guards too, bounded over the whole row as the interpreter expects).
-//  y >= n_chunks: guards 8 (y - n_chunks) .. +7, one work-item per (group of `yrows` rows,
-//    256-pixel tile), evaluated with XMIN / XMAX = the tile's ends and YMIN / YMAX = the group's
-//    (a bound over 256 x 8 pixels skips far more than one over the row); writes its byte of
+//  y >= n_chunks: guards 8 (y - n_chunks) .. +7, one work-item per rectangle (group of `yrows` rows,
+//    run of jit_guard_geom().gw pixels), evaluated with XMIN / XMAX = the run's ends and YMIN / YMAX = the group's
+//    (a bound over a rectangle skips far more than one over the row); writes its byte of
 //    the rectangle's guard words (64 guards per word).  yrows = 1 when some guard reads Y.  Small
 //    jobs on purpose: each is one long dependent chain, and only more wavefronts hide that.
 // One launch for both: the few y-value wavefronts run in the shadow of the guard ones.
@@ -583,6 +613,7 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
     const RowTapeDeps deps = row_tape_deps(P);
     const uint32_t n_ynum = numeric_yvals(P), n_gwords = jit_guard_words(P);
     const GuardPlan plan = jit_guard_plan(P);
+    const GuardGeom geom = jit_guard_geom(P);
     const uint32_t n_gjobs = n_gwords ? (plan.n_pos + 7) / 8 : 0;                // 8 bits = one byte of a word per job
     if (n_gjobs_out) *n_gjobs_out = n_gjobs;
     // the interpreter (which drains deferred tiles from the same y-value table) does read the guard values
@@ -605,7 +636,7 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
          "    // guard jobs first in the grid (they are the long ones: the y-value jobs fill in behind them): job = the switch index\n"
          "    const unsigned mr_job = blockIdx.y < " + std::to_string(n_gjobs) + "u ? " + std::to_string(chunks.size()) + "u + blockIdx.y : blockIdx.y - " + std::to_string(n_gjobs) + "u;\n"
          "    if (mr_job < " + std::to_string(chunks.size()) + "u) {\n"
-         + std::string(getenv("MARAY_JIT_ROW_PART") && getenv("MARAY_JIT_ROW_PART")[0] == '2' ? "    return;      // measurement: guard jobs only (wrong pixels!)\n" : "") +
+         + std::string(getenv("MARAY_JIT_ROW_PART") && (getenv("MARAY_JIT_ROW_PART")[0] == '2' || getenv("MARAY_JIT_ROW_PART")[0] == '3') ? "    return;      // measurement: guard jobs only (wrong pixels!)\n" : "") +
          "    // y values: a work-item per row.  A lane's values go to LDS ([value][row], values 65 apart: no bank conflicts either\n"
          "    // way) and leave as rows of the table, a chunk's values side by side: full cache lines.  Stored from the registers, a\n"
          "    // wavefront's store touches 64 lines for 8 bytes each -- 1.2 M partial writes per frame, which is what the kernel\n"
@@ -636,13 +667,14 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
          "    }\n"
          "    return;\n    }\n";
     if (n_gwords) {
-        if (getenv("MARAY_JIT_ROW_PART") && getenv("MARAY_JIT_ROW_PART")[0] == '1') s += "    return;      // measurement: y-value jobs only (wrong pixels!)\n";
+        if (getenv("MARAY_JIT_ROW_PART") && (getenv("MARAY_JIT_ROW_PART")[0] == '1' || getenv("MARAY_JIT_ROW_PART")[0] == '3')) s += "    return;      // measurement: y-value jobs only (wrong pixels!)\n";
         s += "    // guards: (row group, tile), the tiles of a group adjacent\n"
              "    const unsigned n_groups = (rows + yrows - 1u) / yrows;\n"
              "    if (item >= (unsigned long long)n_groups * n_tx) return;\n"
              "    const unsigned grp = (unsigned)(item / n_tx), tile = (unsigned)(item % n_tx);\n"
              "    const unsigned r = grp * yrows, r_last = r + yrows - 1u < rows - 1u ? r + yrows - 1u : rows - 1u;      // launch rows of the group\n"
-             "    const unsigned xlo = tile * 256u, xhi = xlo + 255u < w - 1u ? xlo + 255u : w - 1u;\n"
+             "    // (n_tx counts rectangles here; the last 256-pixel tile of a ragged row may own rectangles past the edge: they bound the last pixel)\n"
+             "    const unsigned xlo_ = tile * " + std::to_string(geom.gw) + "u, xlo = xlo_ < w - 1u ? xlo_ : w - 1u, xhi = xlo_ + " + std::to_string(geom.gw - 1) + "u < w - 1u ? xlo_ + " + std::to_string(geom.gw - 1) + "u : w - 1u;\n"
              "    // a group never straddles two row blocks (the host picks yrows | blk_rows), so its image rows are consecutive\n"
              "    const double Y = (double)(y0 + (r / blk_rows) * blk_stride + r % blk_rows), XMIN = (double)xlo, XMAX = (double)xhi;\n"
              "    const double YMIN = Y, YMAX = Y + (double)(r_last - r);\n"
@@ -779,6 +811,9 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
     const uint32_t n_gwords = jit_guard_words(P);
     E.ignore_row_guards = n_gwords == 0;
     const GuardPlan plan = jit_guard_plan(P);
+    const GuardGeom geom = jit_guard_geom(P);
+    const uint32_t sub = 256u / geom.gw;                   // guard rectangles per 256-pixel tile (> 1: their words are taken per pass)
+    const std::string tw = std::to_string(sub * n_gwords);  // guard words per tile
     const uint32_t gw_max = jit_gw_inline_max();
     if (n_gwords) { E.guard_first = n_ynum; E.guard_words = n_gwords; E.plan = &plan; E.gw_lanes = true; E.gw_inline_max = gw_max; }
     const bool defer = may_defer_tiles(P);
@@ -836,10 +871,11 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
          "    const double Y = (double)(blk_stride == 0u ? y0 + row_base + r : y0 + ((row_base + r) / blk_rows) * blk_stride + (row_base + r) % blk_rows);\n"
          "    (void)Y; (void)tex; (void)gbits; (void)yrows; (void)tile_list; (void)tile_base;\n";
     if (n_gwords)
-        s += "    const unsigned long long mr_gbase0 = (unsigned long long)(gbits + ((size_t)((row_base + r) >> (yrows == 8u ? 3u : 0u)) * n_tx + tile0) * " + nw + "u);\n";
+        s += "    const unsigned long long mr_gbase0 = (unsigned long long)(gbits + ((size_t)((row_base + r) >> __builtin_ctz(yrows)) * n_tx + tile0) * " + tw + "u);\n";
     if (gw_vgpr)
-        s += "    const unsigned mr_gn = (n_tx - tile0 < tiles ? n_tx - tile0 : tiles) * " + nw + "u;       // <= 64: the host bounds `tiles`\n"
-             "    const unsigned long long mr_gv = mr_lane < mr_gn ? ((const unsigned long long *)mr_gbase0)[mr_lane] : 0ull;\n";
+        s += "    const unsigned mr_gn = (n_tx - tile0 < tiles ? n_tx - tile0 : tiles) * " + tw + "u;       // <= 64: the host bounds `tiles`\n"
+             "    const unsigned long long mr_gv = mr_lane < mr_gn ? ((const unsigned long long *)mr_gbase0)[mr_lane] : 0ull;\n" +
+             (sub > 1 ? "    const unsigned long long mr_gnz = mr_ballot(mr_gv != 0ull);            // which of the strip's words have a bit set\n" : "");
     s += "    const bool mr_wide = rgb64 == nullptr;                                   // wide variants: element e of lane l is pixel x0 + 4 l + e, else x0 + 64 e + l\n"
          "    const unsigned mr_xl = mr_wide ? 4u * mr_lane : mr_lane, mr_xs = mr_wide ? 1u : 64u;\n"
          "    const unsigned mr_src = (mr_lane * 4u) / 3u, mr_shift = ((mr_lane * 4u) % 3u) * 8u;   // RGB8 packing of one 64-pixel run\n"
@@ -857,7 +893,8 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
             s += "    unsigned long long mr_gbase = mr_gbase0;\n"
                  "    asm volatile(\"\" : \"+s\"(mr_gbase));\n"
                  "    const mr_gptr mr_gk = (mr_gptr)mr_gbase + t * " + nw + "u;\n";
-        if (gw_vgpr)
+        if (gw_vgpr && sub > 1) ;            // narrow rectangles: a pass takes the words of its own rectangle
+        else if (gw_vgpr)
             for (uint32_t j = 0; j < n_gwords; j++)
                 s += "    mr_mask gq" + std::to_string(j) + " = mr_lane64(mr_gv, t * " + nw + "u + " + std::to_string(j) + "u);\n";
         else if (n_gwords <= gw_max)
@@ -894,7 +931,13 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
     // the tile's guard words, opaque anew in every pass: left visible, all their bit tests are loop invariants too
     // (168 booleans for chess, hoisted and spilled to VGPR lanes)
     std::string gq_pass;
-    if (n_gwords && n_gwords <= gw_max)
+    if (n_gwords && sub > 1)
+        for (uint32_t j = 0; j < n_gwords; j++) {
+            const std::string k = std::to_string(j);
+            gq_pass += "    mr_mask gq" + k + " = mr_lane64(mr_gv, (t * " + std::to_string(sub) + "u + (e >> " + std::to_string(sub == 4 ? 0 : 1) + "u)) * " + nw + "u + " + k + "u);\n"
+                       "    asm volatile(\"\" : \"+s\"(gq" + k + "));\n";
+        }
+    else if (n_gwords && n_gwords <= gw_max)
         for (uint32_t j = 0; j < n_gwords; j++) {
             const std::string k = std::to_string(j);
             gq_pass += "    asm volatile(\"\" : \"+s\"(gq" + k + "));\n";
@@ -903,7 +946,7 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
         for (uint32_t j = 0; j < (n_gwords + 63) / 64; j++)
             gq_pass += "    asm volatile(\"\" : \"+v\"(mr_gt" + std::to_string(j) + "));\n";
     const std::string wide_open =
-        "    {\n" + opaque + gq_pass +
+        "    {\n" + opaque + (sub > 1 ? std::string() : gq_pass) +
         "    const unsigned xa = x0 + mr_xl;                                        // this lane's first pixel\n"
         "    const mr_d X((double)xa, (double)(xa + mr_xs), (double)(xa + 2u * mr_xs), (double)(xa + 3u * mr_xs));\n"
         "    mr_d o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"
@@ -962,7 +1005,9 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
 
     if (n_gwords) {
         // the variant of a tile with no guard bit set, four pixels per lane
-        if (n_gwords <= gw_max) {
+        if (sub > 1)
+            s += "    if (((mr_gnz >> (t * " + tw + "u)) & " + std::to_string((1ull << (sub * n_gwords)) - 1ull) + "ull) == 0ull) {\n";
+        else if (n_gwords <= gw_max) {
             std::string any = "gq0";
             for (uint32_t j = 1; j < n_gwords; j++) any += " | gq" + std::to_string(j);
             s += "    if ((" + any + ") == 0ull) {\n";
@@ -1003,7 +1048,7 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
             // (same-wave traffic: no barrier) and a whole aligned tile is stored as a dwordx3 per lane.
             // MARAY_JIT_NARROW=2: two passes of 128 pixels, two pixels per lane (measurement knob).
             const char *env_nw = getenv("MARAY_JIT_NARROW");
-            const bool two = env_nw && env_nw[0] == '2';
+            const bool two = env_nw && env_nw[0] == '2' && sub == 1;
             if (two) { E.td = "mr_d2"; E.tm = "mr_m2"; }
             s += "    const bool mr_fast = rgb8 && x0 + 256u <= w && ((size_t)(rgb8 + (row_px + x0) * 3) & 3u) == 0u;      // wave-uniform\n"
                  "    _Pragma(\"unroll 1\") for (unsigned e = 0; e < " + std::string(two ? "2u" : "4u") + "; e++) {\n" + opaque + gq_pass +
@@ -1015,7 +1060,21 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
                         "    double o0 = 0.0, o1 = 0.0, o2 = 0.0;\n") +
                  "    float mr_defer = 0.0f;\n"
                  "    (void)X; (void)mr_defer;\n";
+            const char *env_ps = getenv("MARAY_JIT_PASS_SKY");
+            const bool pass_sky = sub > 1 && env_ps && env_ps[0] == '1';       // measured: no gain (chess 36.5 against 36.1 us), off
+            if (pass_sky) {
+                // a pass none of whose rectangle's guard bits is set (the tile's other passes have some): the section with every
+                // guarded region the literal 0, instead of a walk through the skeleton of bit tests that all fail
+                std::string any = "gq0";
+                for (uint32_t j = 1; j < n_gwords; j++) any += " | gq" + std::to_string(j);
+                s += "    if ((" + any + ") == 0ull) {\n";
+                E.assume_guards_zero = true;
+                E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+                E.assume_guards_zero = false;
+                s += "    } else {\n";
+            }
             E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+            if (pass_sky) s += "    }\n";
             E.td = "double"; E.tm = "mr_mask";
             s += defer_pass;
             if (two)
@@ -1506,7 +1565,7 @@ struct JitBackend final : Backend {
     unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;      // time_rows without a caller's buffer
     HostPipe pipe;                      // streams + staging of the host-raster entry points
     hipStream_t own_stream = nullptr;   // = pipe's compute stream
-    uint32_t n_row_chunks = 1, n_gwords = 0, n_gjobs = 0, guard_rows = 1;
+    uint32_t n_row_chunks = 1, n_gwords = 0, n_gjobs = 0, guard_rows = 1, guard_sub = 1;       // guard_sub: guard rectangles per 256-pixel tile
     uint32_t n_cu = 256;
     // launch-time tuning knobs, read once when the context is created
     bool k_overlap = false, k_coop = false, k_persist = false, wide_all = false;
@@ -1563,6 +1622,7 @@ struct JitBackend final : Backend {
             n_gwords = jit_guard_words(prog);
             if (n_gwords && !(getenv("MARAY_JIT_NO_ORDER") && getenv("MARAY_JIT_NO_ORDER")[0] == '1')) HIP_TRY(hipModuleGetFunction(&f_order, mod_rows, "maray_jit_order"));
             guard_rows = jit_guard_rows(prog);
+            guard_sub = 256u / jit_guard_geom(prog).gw;
 
         }
         pipe.init(dev);
@@ -1622,7 +1682,7 @@ struct JitBackend final : Backend {
             if (overlap && pix_done_set[b]) HIP_TRY(hipStreamWaitEvent(rs, pix_done[b], 0));       // the reader of this set has finished
             ensure(d_yvals2[b], yvals_cap2[b], (size_t)rows_total * std::max<uint32_t>(P.n_yvals, 1));
             const size_t had = gbits_cap2[b];
-            ensure(d_gbits2[b], gbits_cap2[b], (size_t)n_groups * ((w + 255) / 256) * std::max<uint32_t>(n_gwords, 1));
+            ensure(d_gbits2[b], gbits_cap2[b], (size_t)n_groups * ((w + 255) / 256) * guard_sub * std::max<uint32_t>(n_gwords, 1));
             // bits past the last guard belong to no job and are never written: zero them once (the pixel kernel tests whole words)
             if (gbits_cap2[b] != had) HIP_TRY(hipMemsetAsync(d_gbits2[b], 0, gbits_cap2[b] * sizeof(unsigned long long), rs));
             cur_set = b;
@@ -1633,8 +1693,8 @@ struct JitBackend final : Backend {
         unsigned n_yvals = P.n_yvals;
         if (rows_pass && P.n_row_ops) {
             unsigned yy0 = y0, rr = rows_total, ww = w;
-            unsigned n_tx_ = (w + 255) / 256;
-            // guards: one item per (group of yrows rows, 256-pixel tile); y values: one per row
+            unsigned n_tx_ = (w + 255) / 256 * guard_sub;
+            // guards: one item per rectangle (group of yrows rows, run of 256 / guard_sub pixels); y values: one per row
             const uint64_t items = std::max<uint64_t>(n_gwords ? (uint64_t)n_groups * n_tx_ : 0, rows_total);
             const unsigned bs = k_row_block;
             if ((items + bs - 1) / bs > 0x7FFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
@@ -1658,7 +1718,7 @@ struct JitBackend final : Backend {
                 // an earlier launch (another geometry) may still be reading the table: its pixel kernel first
                 if (overlap && pix_done_set[b ^ 1]) HIP_TRY(hipStreamWaitEvent(rs, pix_done[b ^ 1], 0));
                 ensure(d_order, order_cap, (size_t)rows_total);
-                unsigned rr = rows_total, n_tx_ = (w + 255) / 256;
+                unsigned rr = rows_total, n_tx_ = (w + 255) / 256 * guard_sub;
                 void *oargs[] = {&d_gbits, &d_order, &rr, &n_tx_, &yrows};
                 HIP_TRY(hipModuleLaunchKernel(f_order, 1, 1, 1, 256, 1, 1, n_groups * 4, rs, oargs, nullptr));
                 order_key[0] = key[0]; order_key[1] = key[1]; order_key[2] = key[2];
@@ -1684,7 +1744,7 @@ struct JitBackend final : Backend {
             const bool coop = k_coop;
             tiles = coop || wide_all ? 8 : 2;
             if (k_tiles) tiles = std::min(64u, k_tiles);
-            if (n_gwords && n_gwords <= jit_gw_inline_max()) tiles = std::min(tiles, 64u / n_gwords);
+            if (n_gwords && n_gwords <= jit_gw_inline_max()) tiles = std::min(tiles, 64u / (n_gwords * guard_sub));
             tiles = std::max(1u, std::min(tiles, n_tx));
             gx = coop ? (n_tx + tiles - 1) / tiles : (n_tx + 4 * tiles - 1) / (4 * tiles);
         } else {

@@ -462,12 +462,12 @@ def test_row_blocks_in_one_launch_equal_the_blocks_one_by_one():
 
 
 def test_guards_per_group_of_rows_with_ragged_ranges(chess_bytes):
-    """The specialised path evaluates chess's guards once per 8 rows x 256 pixels; ranges that do not start or end on
-    a multiple of 8 have a partial group at the end.  Against the interpreter, which evaluates them row by row."""
+    """The specialised path evaluates chess's guards once per rectangle of 32 rows x 64 pixels; ranges that do not start
+    or end on a multiple of 32 have a partial group at the end.  Against the interpreter, which evaluates them row by row."""
     tape = M.Scene(chess_bytes).lower()
     jit = M.Context(tape, backend=M.BACKEND_JIT)
     ref = M.Context(tape, backend=M.BACKEND_TAPE_SMEM)
-    for y0, y1 in ((5, 1021), (509, 516), (700, 713)):
+    for y0, y1 in ((5, 1021), (509, 516), (700, 713), (481, 545), (512, 577)):
         a8, a64 = jit.render_rows(1024, 1024, y0, y1)
         b8, b64 = ref.render_rows(1024, 1024, y0, y1)
         assert np.array_equal(a8, b8) and same_f64(a64, b64), (y0, y1)
@@ -478,7 +478,8 @@ def test_guards_per_group_of_rows_with_ragged_ranges(chess_bytes):
 def test_specialised_kernel_variants_selected_by_tuning_knobs(chess_bytes, monkeypatch):
     """Paths the default build of chess does not take.  Of the default layout (a wavefront per 256-pixel tile): the block's
     four wavefronts side by side on a busy tile, guard words by scalar loads, the whole section four pixels per lane, y
-    values all numeric, no private ROW stream, other strip lengths.  And the first layout (one pixel per lane throughout,
+    values all numeric, no private ROW stream, other strip lengths, other guard rectangles (256 x 8 was round 1's), a
+    pass-level sky variant, two pixels per lane on busy tiles.  And the first layout (one pixel per lane throughout,
     MARAY_JIT_PX=1) with its own knobs: y values staged in LDS, guards compiled away, one tile per block, literal constants."""
     g = json.load(open(os.path.join(GOLDEN, 'chess_1024.json')))
     tape = M.Scene(chess_bytes).lower()
@@ -488,6 +489,9 @@ def test_specialised_kernel_variants_selected_by_tuning_knobs(chess_bytes, monke
                 {'MARAY_JIT_ROW_GUARDS': '0'}, {'MARAY_JIT_KTAB': '0'}, {'MARAY_JIT_NO_ORDER': '1'}, {'MARAY_JIT_ROW_CHUNK_OPS': '300'},
                 {'MARAY_JIT_PERSIST': '1'}, {'MARAY_JIT_PERSIST': '1', 'MARAY_JIT_TILES': '3', 'MARAY_JIT_BLOCKS_PER_CU': '2'},
                 {'MARAY_JIT_GW_MANY': '1'}, {'MARAY_JIT_GW_MANY': '1', 'MARAY_JIT_TILES': '5'},
+                {'MARAY_JIT_GUARD_W': '256', 'MARAY_JIT_GUARD_H': '8'}, {'MARAY_JIT_GUARD_W': '128', 'MARAY_JIT_GUARD_H': '16', 'MARAY_JIT_TILES': '3'},
+                {'MARAY_JIT_GUARD_W': '64', 'MARAY_JIT_GUARD_H': '128'}, {'MARAY_JIT_PASS_SKY': '1'}, {'MARAY_JIT_GUARD_W': '256', 'MARAY_JIT_NARROW': '2'},
+                {'MARAY_JIT_TILES': '7'},
                 px1, dict(px1, MARAY_JIT_YLDS='1'), dict(px1, MARAY_JIT_ROW_GUARDS='0'), dict(px1, MARAY_JIT_TILES='1'), dict(px1, MARAY_JIT_KTAB='0'),
                 dict(px1, MARAY_JIT_ROW_BLOCK='64', MARAY_JIT_TILES='3'), dict(px1, MARAY_JIT_GLDS='0'), dict(px1, MARAY_JIT_ROWS_REVERSED='1')):
         for k, v in env.items():
