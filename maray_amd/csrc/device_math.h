@@ -39,7 +39,29 @@ MARAY_DEV double mr_neg01(mr_mask m) { return mr_mask_f64(m, 0xbff00000u, 0x8000
 MARAY_DEV double mr_neg(double a) { return -a; }
 MARAY_DEV double mr_abs(double a) { return __builtin_fabs(a); }
 MARAY_DEV double mr_recip(double a) { return 1.0 / a; }
-MARAY_DEV double mr_sqrt(double a) { return __builtin_sqrt(a); }
+// Sqrt: the compiler's correctly rounded expansion scales its argument by 2^256 when it is below 2^-767 (and the root
+// back by 2^-128) so that the Newton steps keep their precision: a compare, two selects and two v_ldexp_f64 per lane for
+// a case pixels do not meet.  Here the wavefront asks once whether any lane needs the scaling (zeros do not: the final
+// class select returns them) and otherwise runs the same steps on the bare argument -- identical bits, 14 instructions
+// instead of 18.
+MARAY_DEV bool mr_sqrt_needs_scaling(double a)          // wave-uniform
+{
+    return __builtin_expect(mr_ballot(a < 0x1p-767) != 0ull, 0) && mr_ballot(a < 0x1p-767 && a != 0.0) != 0ull;
+}
+MARAY_DEV double mr_sqrt_unscaled(double a)
+{
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    double d = __builtin_fma(-g, g, a);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, a);
+    g = __builtin_fma(d, h, g);
+    return __builtin_amdgcn_class(a, 0x260) ? a : g;         // +-0 and +inf are their own roots
+}
+MARAY_DEV double mr_sqrt(double a) { return mr_sqrt_needs_scaling(a) ? __builtin_sqrt(a) : mr_sqrt_unscaled(a); }
 // Step (:644-647): NaN -> 0, -0.0 -> 1.
 MARAY_DEV double mr_step(double a) { return a >= 0.0 ? 1.0 : 0.0; }
 // f64::max / f64::min (:655-658): NaN-ignoring = v_max_f64 / v_min_f64
@@ -143,7 +165,12 @@ MARAY_DEV mr_m mr_stepsin_bounded_m(const mr_d &v) { return mr_m(mr_stepsin_boun
 MARAY_DEV mr_d mr_neg(const mr_d &v) { return MR_EACH1(mr_neg, v); }
 MARAY_DEV mr_d mr_abs(const mr_d &v) { return MR_EACH1(mr_abs, v); }
 MARAY_DEV mr_d mr_recip(const mr_d &v) { return MR_EACH1(mr_recip, v); }
-MARAY_DEV mr_d mr_sqrt(const mr_d &v) { return MR_EACH1(mr_sqrt, v); }
+MARAY_DEV mr_d mr_sqrt(const mr_d &v)           // one question for the four elements: their Newton chains interleave
+{
+    const double least = __builtin_fmin(__builtin_fmin(v.a, v.b), __builtin_fmin(v.c, v.d));      // (NaNs drop out: they need no scaling)
+    if (__builtin_expect(mr_ballot(least < 0x1p-767) != 0ull, 0)) return MR_EACH1(mr_sqrt, v);     // some element is tiny, zero or negative: ask per element
+    return MR_EACH1(mr_sqrt_unscaled, v);
+}
 MARAY_DEV mr_d mr_sin(const mr_d &v) { return MR_EACH1(mr_sin, v); }
 MARAY_DEV mr_d mr_sin_bounded(const mr_d &v) { return MR_EACH1(mr_sin_bounded, v); }
 MARAY_DEV mr_d mr_exp(const mr_d &v) { return MR_EACH1(mr_exp, v); }

@@ -143,7 +143,7 @@ struct Emitter {
     const GuardPlan *plan = nullptr;            // guard -> bit(s) (identity when null)
     uint32_t gw_inline_max = 12;
     bool gw_lanes = false;                      // > 12 guard words: lane i of mr_gt<j> holds word 64 j + i of the tile at hand
-    int stage_first = -1;                       // ROW: >= 0: OUT k goes to LDS, ys[(k - stage_first) * 65 + lane] (jit_source_rows)
+    int stage_first = -1;                       // ROW: >= 0: OUT k goes to LDS, ys[(k - stage_first) * 68 + lane] (jit_source_rows)
     std::string td = "double", tm = "mr_mask";  // types of a value / a boolean in the generated text ("mr_d" / "mr_m": four pixels per lane)
     std::vector<double> ktab_vals;
     std::unordered_map<uint64_t, uint32_t> ktab_block;
@@ -306,7 +306,7 @@ struct Emitter {
                 }
                 else
                     out += pixel ? "    o" + std::to_string(aux) + " = " + a + ";\n"
-                           : stage_first >= 0 ? "    ys[" + std::to_string((aux - (uint32_t)stage_first) * 65) + "u + mr_lane] = " + a + ";\n"
+                           : stage_first >= 0 ? "    ys[" + std::to_string((aux - (uint32_t)stage_first) * 68) + "u + mr_lane] = " + a + ";\n"
                                               : "    yout[" + std::to_string(aux) + "] = " + a + ";\n";
                 continue;
             }
@@ -510,7 +510,7 @@ struct RowChunks {
     std::vector<std::vector<uint64_t>> tapes;
     std::vector<uint32_t> first, count;
 };
-static const uint32_t ROW_CHUNK_MAX_OUTS = 16;      // x 65 x 8 B of LDS per wavefront
+static const uint32_t ROW_CHUNK_MAX_OUTS = 16;      // x 68 x 8 B of LDS per wavefront
 
 RowChunks split_row_tape(const maray_program &P, const RowTapeDeps &d, uint32_t out_limit)
 {
@@ -631,23 +631,23 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
          "                                                                 const MarayTex *__restrict__ tex,\n"
          "                                                                 unsigned y0, unsigned rows, unsigned n_yvals, unsigned w, unsigned n_tx,\n"
          "                                                                 unsigned blk_rows, unsigned blk_stride, unsigned yrows)\n{\n"
-         "    const unsigned long long item = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;\n"
+         "    const unsigned item = blockIdx.x * blockDim.x + threadIdx.x;         // (the host keeps the items of a launch below 2^32)\n"
          "    (void)tex; (void)gbits; (void)n_tx;\n"
          "    // guard jobs first in the grid (they are the long ones: the y-value jobs fill in behind them): job = the switch index\n"
          "    const unsigned mr_job = blockIdx.y < " + std::to_string(n_gjobs) + "u ? " + std::to_string(chunks.size()) + "u + blockIdx.y : blockIdx.y - " + std::to_string(n_gjobs) + "u;\n"
          "    if (mr_job < " + std::to_string(chunks.size()) + "u) {\n"
          + std::string(getenv("MARAY_JIT_ROW_PART") && (getenv("MARAY_JIT_ROW_PART")[0] == '2' || getenv("MARAY_JIT_ROW_PART")[0] == '3') ? "    return;      // measurement: guard jobs only (wrong pixels!)\n" : "") +
-         "    // y values: a work-item per row.  A lane's values go to LDS ([value][row], values 65 apart: no bank conflicts either\n"
-         "    // way) and leave as rows of the table, a chunk's values side by side: full cache lines.  Stored from the registers, a\n"
+         "    // y values: a work-item per row.  A lane's values go to LDS ([value][row], values 68 apart) and leave as rows of the\n"
+         "    // table, a chunk's values side by side: full cache lines.  Stored from the registers, a\n"
          "    // wavefront's store touches 64 lines for 8 bytes each -- 1.2 M partial writes per frame, which is what the kernel\n"
          "    // then waits for (11.8 us; the arithmetic needs 2).\n"
-         "    __shared__ double mr_ys[" + std::to_string(row_block / 64) + " * " + std::to_string(ROW_CHUNK_MAX_OUTS * 65) + "];\n"
+         "    __shared__ double mr_ys[" + std::to_string(row_block / 64) + " * " + std::to_string(ROW_CHUNK_MAX_OUTS * 68) + "];\n"
          "    const unsigned mr_lane = threadIdx.x & 63u;\n"
-         "    double *ys = mr_ys + (threadIdx.x >> 6) * " + std::to_string(ROW_CHUNK_MAX_OUTS * 65) + "u;\n"
-         "    const unsigned long long row0 = item - mr_lane;                       // first row of this wavefront\n"
+         "    double *ys = mr_ys + (threadIdx.x >> 6) * " + std::to_string(ROW_CHUNK_MAX_OUTS * 68) + "u;\n"
+         "    const unsigned row0 = item - mr_lane;                                 // first row of this wavefront\n"
          "    if (row0 >= rows) return;                                            // whole wavefronts only: every lane helps to store\n"
-         "    const unsigned r = (unsigned)item;\n"
-         "    const double Y = (double)(y0 + (r / blk_rows) * blk_stride + r % blk_rows), XMIN = 0.0, XMAX = (double)(w - 1u);\n"
+         "    const unsigned r = item;\n"
+         "    const double Y = (double)(blk_stride == 0u ? y0 + r : y0 + (r / blk_rows) * blk_stride + r % blk_rows), XMIN = 0.0, XMAX = (double)(w - 1u);\n"
          "    const double YMIN = Y, YMAX = Y;\n"
          "    (void)Y; (void)XMIN; (void)XMAX; (void)YMIN; (void)YMAX; (void)yrows;\n"
          "    unsigned mr_k0 = 0u, mr_kn = 0u;\n"
@@ -661,22 +661,26 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
     }
     s += "    }\n"
          "    __builtin_amdgcn_wave_barrier();                                       // same wavefront: LDS keeps its order\n"
-         "    for (unsigned e = mr_lane; e < 64u * mr_kn; e += 64u) {\n"
-         "        const unsigned row = e / mr_kn, j = e - row * mr_kn;\n"
-         "        if (row0 + row < rows) yvals[(size_t)(row0 + row) * n_yvals + mr_k0 + j] = ys[j * 65u + row];\n"
+         "    // lane 16 q + j stores value j of the rows 4 i + q, i = 0 .. 15: an instruction writes four rows of the chunk\n"
+         "    const unsigned mr_j = mr_lane & 15u, mr_q = mr_lane >> 4;\n"
+         "    double *mr_dst = yvals + (size_t)(row0 + mr_q) * n_yvals + mr_k0 + mr_j;\n"
+         "    const size_t mr_step = (size_t)4u * n_yvals;\n"
+         "    if (mr_j < mr_kn) {\n"
+         "        _Pragma(\"unroll\") for (unsigned i = 0; i < 16u; i++)\n"
+         "            if (row0 + 4u * i + mr_q < rows) mr_dst[i * mr_step] = ys[mr_j * 68u + 4u * i + mr_q];\n"
          "    }\n"
          "    return;\n    }\n";
     if (n_gwords) {
         if (getenv("MARAY_JIT_ROW_PART") && (getenv("MARAY_JIT_ROW_PART")[0] == '1' || getenv("MARAY_JIT_ROW_PART")[0] == '3')) s += "    return;      // measurement: y-value jobs only (wrong pixels!)\n";
         s += "    // guards: (row group, tile), the tiles of a group adjacent\n"
              "    const unsigned n_groups = (rows + yrows - 1u) / yrows;\n"
-             "    if (item >= (unsigned long long)n_groups * n_tx) return;\n"
-             "    const unsigned grp = (unsigned)(item / n_tx), tile = (unsigned)(item % n_tx);\n"
+             "    if (item >= n_groups * n_tx) return;\n"
+             "    const unsigned grp = item / n_tx, tile = item - grp * n_tx;\n"
              "    const unsigned r = grp * yrows, r_last = r + yrows - 1u < rows - 1u ? r + yrows - 1u : rows - 1u;      // launch rows of the group\n"
              "    // (n_tx counts rectangles here; the last 256-pixel tile of a ragged row may own rectangles past the edge: they bound the last pixel)\n"
              "    const unsigned xlo_ = tile * " + std::to_string(geom.gw) + "u, xlo = xlo_ < w - 1u ? xlo_ : w - 1u, xhi = xlo_ + " + std::to_string(geom.gw - 1) + "u < w - 1u ? xlo_ + " + std::to_string(geom.gw - 1) + "u : w - 1u;\n"
              "    // a group never straddles two row blocks (the host picks yrows | blk_rows), so its image rows are consecutive\n"
-             "    const double Y = (double)(y0 + (r / blk_rows) * blk_stride + r % blk_rows), XMIN = (double)xlo, XMAX = (double)xhi;\n"
+             "    const double Y = (double)(blk_stride == 0u ? y0 + r : y0 + (r / blk_rows) * blk_stride + r % blk_rows), XMIN = (double)xlo, XMAX = (double)xhi;\n"
              "    const double YMIN = Y, YMAX = Y + (double)(r_last - r);\n"
              "    unsigned long long gacc = 0ull;\n"
              "    double *yout = nullptr;\n"
@@ -699,7 +703,7 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
             s += "    } break;\n";
         }
         s += "    }\n"
-             "    ((unsigned char *)gbits)[item * " + std::to_string(8 * n_gwords) + "u + (mr_job - " + std::to_string(chunks.size()) + "u)] = (unsigned char)gacc;\n";
+             "    ((unsigned char *)gbits)[(size_t)item * " + std::to_string(8 * n_gwords) + "u + (mr_job - " + std::to_string(chunks.size()) + "u)] = (unsigned char)gacc;\n";
     }
     s += "}\n";
     // Launch order of the PIXEL kernel: groups of rows by what they cost, dearest first, so that the tail of the launch is
@@ -797,11 +801,12 @@ bool jit_persist()
 static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
 {
     Emitter E(P);
-    // Wave-level SKIP ops over fewer than 24 ops are ignored: a busy tile is bound by the scalar unit (branches, bit tests,
-    // mask algebra: 0.59 SALU instructions per cycle and CU against 35 % VALU issue), and a short region's test and branch
-    // cost that unit more than its ops cost the vector one (chess board 111 -> 104 us per 16.7 Mpx; 8 / 12 / 16 / 24 / 40
-    // ops: 108 / 107 / 106 / 104 / 106).
-    E.min_region = 24;
+    // Wave-level SKIP ops over fewer than 12 instructions' worth of ops are ignored: a busy tile is bound by the scalar unit
+    // (branches, bit tests, mask algebra: 0.59 SALU instructions per cycle and CU against 35 % VALU issue), and a short
+    // region's test and branch cost that unit more than its ops cost the vector one (chess board, us per 16.7 Mpx, with
+    // guards per 256 x 8 pixels: none ignored 111, 24: 104; with guards per 64 x 32: 8 / 12 / 16 ... 32 / 64 / 200:
+    // 83.3 / 82.4 / 84.7 / 85.4 / 128).
+    E.min_region = 12;
     if (const char *e_ = getenv("MARAY_JIT_MIN_REGION")) E.min_region = (uint32_t)atoi(e_);
     E.ybool = jit_bool_yvals(P);
     std::string &s = E.out;
@@ -1697,7 +1702,7 @@ struct JitBackend final : Backend {
             // guards: one item per rectangle (group of yrows rows, run of 256 / guard_sub pixels); y values: one per row
             const uint64_t items = std::max<uint64_t>(n_gwords ? (uint64_t)n_groups * n_tx_ : 0, rows_total);
             const unsigned bs = k_row_block;
-            if ((items + bs - 1) / bs > 0x7FFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
+            if (items + bs > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
             void *args[] = {&d_yvals, &d_gbits, &d_tex, &yy0, &rr, &n_yvals, &ww, &n_tx_, &blk_rows, &blk_stride, &yrows};
             unsigned gy = n_row_chunks + n_gjobs;
             HIP_TRY(hipModuleLaunchKernel(f_rows, (unsigned)((items + bs - 1) / bs), gy, 1, bs, 1, 1, 0, rs, args, nullptr));

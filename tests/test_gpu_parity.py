@@ -11,7 +11,7 @@ import pytest
 import maray_amd as M
 import scenes
 from conftest import GOLDEN
-from marayb import encode, let_, add, mul, nat, var_id, x, y, max_, min_, step, sub, div, recip, neg, sqrt, abs_
+from marayb import encode, let_, add, mul, nat, var_id, x, y, max_, min_, step, sub, div, recip, neg, sqrt, abs_, exp
 from oracle_ffi import Scene as OScene
 from test_lowering import same_f64
 
@@ -296,6 +296,24 @@ def test_corner_cases():
     with pytest.raises(M.MarayError):
         ctx.render_rows(4, 4, 3, 9)
     ctx.close()
+
+
+def test_sqrt_of_tiny_zero_negative_and_infinite_arguments():
+    """Sqrt scales arguments below 2^-767 (the Newton steps would lose bits); the device asks once per wavefront whether
+    any lane needs that (device_math.h, mr_sqrt).  Subnormals, values either side of the threshold, zeros of both signs,
+    negatives, inf and NaN: mixed inside a wavefront (they depend on x), uniform over it (they depend on y only, which
+    also runs them in the ROW kernel), and in a 4-op scene that takes the four-pixels-per-lane form."""
+    tiny = exp(neg(add(mul(x(), nat(5)), nat(400))))                  # e^-400 ... e^-1675: 1e-174 down through the subnormals to 0
+    tiny_y = exp(neg(add(mul(y(), nat(90)), nat(380))))
+    edge = mul(exp(neg(nat(532))), add(nat(1), mul(x(), recip(nat(64)))))       # 9.0e-232 ... 4.5e-231: crosses 2^-767 = 1.29e-231 at x = 27
+    signed = mul(sub(x(), nat(100)), exp(neg(nat(700))))                       # negative, -0 / +0 at x = 100, positive: all tiny
+    c = [sqrt(tiny), sqrt(edge), sqrt(signed)]
+    gpu_vs_oracle(encode((256, 6), c), 256, 6, [(0, 6)])
+    c = [sqrt(tiny_y), sqrt(add(tiny_y, mul(x(), nat(0)))), sqrt(recip(sub(x(), nat(7))))]      # uniform tiny; +-inf at x = 7
+    gpu_vs_oracle(encode((300, 9), c), 300, 9, [(0, 9)])
+    gpu_vs_oracle(encode((600, 3), [sqrt(tiny), sqrt(tiny), sqrt(tiny)]), 600, 3, [(0, 3)])      # small program: four pixels per lane
+    nanv = var_id(99)
+    gpu_vs_oracle(encode((128, 2), [sqrt(mul(nanv, x())), sqrt(max_(nanv, signed)), sqrt(edge)]), 128, 2, [(0, 2)])
 
 
 def test_many_live_values_spill_path():
