@@ -143,6 +143,7 @@ struct Emitter {
     const GuardPlan *plan = nullptr;            // guard -> bit(s) (identity when null)
     uint32_t gw_inline_max = 12;
     bool gw_lanes = false;                      // > 12 guard words: lane i of mr_gt<j> holds word 64 j + i of the tile at hand
+    std::string gw_lane_base;                   // narrow rectangles: lane (this expression) + i of mr_gt0 holds word i of the pass's rectangle
     int stage_first = -1;                       // ROW: >= 0: OUT k goes to LDS, ys[(k - stage_first) * 68 + lane] (jit_source_rows)
     std::string td = "double", tm = "mr_mask";  // types of a value / a boolean in the generated text ("mr_d" / "mr_m": four pixels per lane)
     std::vector<double> ktab_vals;
@@ -257,6 +258,7 @@ struct Emitter {
                     // pair, the wave layout) or a word staged in LDS (the first layout)
                     auto word = [&](uint32_t wi) {
                         if (guard_words <= gw_inline_max) return "gq" + std::to_string(wi);
+                        if (gw_lanes && !gw_lane_base.empty()) return "mr_lane64(mr_gt0, " + gw_lane_base + " + " + std::to_string(wi) + "u)";
                         if (gw_lanes) return "mr_lane64(mr_gt" + std::to_string(wi / 64) + ", " + std::to_string(wi % 64) + "u)";
                         return "mr_uniform64(mr_gqt[" + std::to_string(wi) + "])";
                     };
@@ -577,11 +579,13 @@ GuardGeom jit_guard_geom(const maray_program &P)
     if (const char *e_ = getenv("MARAY_JIT_GUARD_H")) { const int v = atoi(e_); if (v == 8 || v == 16 || v == 32 || v == 64 || v == 128) g.gh = (uint32_t)v; }
     const char *env_gw = getenv("MARAY_JIT_GW");
     const char *env_wide = getenv("MARAY_JIT_WIDE");       // (the whole section four pixels per lane tests a tile's bits once)
-    const bool lanes = jit_px() == 4 && !jit_coop() && !jit_persist() && nw <= jit_gw_inline_max() && !(env_gw && !strcmp(env_gw, "sload")) &&
-                       !(env_wide && env_wide[0] == '1');
+    // narrow rectangles: the default PIXEL layout with a strip's words one per lane (<= 12 words per rectangle), or -- more
+    // words -- a tile's words one per lane: a tile's rectangles together then have to fit a wavefront's 64 lanes
+    const bool lanes = jit_px() == 4 && !jit_coop() && !jit_persist() && !(env_gw && !strcmp(env_gw, "sload")) && !(env_wide && env_wide[0] == '1');
     uint32_t want = 64u;
     if (const char *e_ = getenv("MARAY_JIT_GUARD_W")) { const int v = atoi(e_); if (v == 64 || v == 128 || v == 256) want = (uint32_t)v; }
-    while (want < 256u && !(lanes && nw * (256u / want) <= 64u)) want *= 2u;       // the words of one tile at least must fit a wavefront's lanes
+    while (want < 256u && !(lanes && nw * (256u / want) <= 64u)) want *= 2u;
+    if (want == 256u && !getenv("MARAY_JIT_GUARD_H")) g.gh = 8u;      // wide rectangles gain nothing from height (chess, 256 x 8 / 256 x 32: 48.6 / 50.2 us per frame)
     g.gw = want;
     return g;
 }
@@ -905,6 +909,8 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
         else if (n_gwords <= gw_max)
             for (uint32_t j = 0; j < n_gwords; j++)
                 s += "    mr_mask gq" + std::to_string(j) + " = mr_gk[" + std::to_string(j) + "u];\n";
+        else if (sub > 1)   // many words, narrow rectangles: lane i of mr_gt0 holds word i of the tile's rectangles (<= 64 together, jit_guard_geom)
+            s += "    unsigned long long mr_gt0 = mr_lane < " + tw + "u ? ((const unsigned long long *)mr_gbase)[t * " + tw + "u + mr_lane] : 0ull;\n";
         else        // many words: lane i of mr_gt<j> holds word 64 j + i of this tile (one vector load each); a test takes its word with v_readlane
             for (uint32_t j = 0; j < (n_gwords + 63) / 64; j++)
                 s += "    unsigned long long mr_gt" + std::to_string(j) + " = " + std::to_string(64 * j) + "u + mr_lane < " + nw + "u ? ((const unsigned long long *)mr_gbase)[t * " + nw + "u + " +
@@ -936,7 +942,11 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
     // the tile's guard words, opaque anew in every pass: left visible, all their bit tests are loop invariants too
     // (168 booleans for chess, hoisted and spilled to VGPR lanes)
     std::string gq_pass;
-    if (n_gwords && sub > 1)
+    if (n_gwords > gw_max && sub > 1) {
+        gq_pass = "    asm volatile(\"\" : \"+v\"(mr_gt0));\n"
+                  "    const unsigned mr_gsub = (e >> " + std::to_string(sub == 4 ? 0 : 1) + "u) * " + nw + "u;           // first word of this pass's rectangle\n";
+        E.gw_lane_base = "mr_gsub";
+    } else if (n_gwords && sub > 1)
         for (uint32_t j = 0; j < n_gwords; j++) {
             const std::string k = std::to_string(j);
             gq_pass += "    mr_mask gq" + k + " = mr_lane64(mr_gv, (t * " + std::to_string(sub) + "u + (e >> " + std::to_string(sub == 4 ? 0 : 1) + "u)) * " + nw + "u + " + k + "u);\n"
@@ -1010,7 +1020,9 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
 
     if (n_gwords) {
         // the variant of a tile with no guard bit set, four pixels per lane
-        if (sub > 1)
+        if (sub > 1 && n_gwords > gw_max)
+            s += "    if (mr_ballot(mr_gt0 != 0ull) == 0ull) {\n";
+        else if (sub > 1)
             s += "    if (((mr_gnz >> (t * " + tw + "u)) & " + std::to_string((1ull << (sub * n_gwords)) - 1ull) + "ull) == 0ull) {\n";
         else if (n_gwords <= gw_max) {
             std::string any = "gq0";
@@ -1066,7 +1078,7 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
                  "    float mr_defer = 0.0f;\n"
                  "    (void)X; (void)mr_defer;\n";
             const char *env_ps = getenv("MARAY_JIT_PASS_SKY");
-            const bool pass_sky = sub > 1 && env_ps && env_ps[0] == '1';       // measured: no gain (chess 36.5 against 36.1 us), off
+            const bool pass_sky = sub > 1 && n_gwords <= gw_max && env_ps && env_ps[0] == '1';       // measured: no gain (chess 36.5 against 36.1 us), off
             if (pass_sky) {
                 // a pass none of whose rectangle's guard bits is set (the tile's other passes have some): the section with every
                 // guarded region the literal 0, instead of a walk through the skeleton of bit tests that all fail
