@@ -23,7 +23,7 @@ Rank 0 prints ONE JSON line:
 Roofline: SURVEY.md 8(d) gives two per-pixel figures for this path, 3 bytes of
 mandatory HBM traffic (the RGB8 pixel written) and 10,241 f64 ops (the census of
 the scene's DAG).  The kernel evaluates the scene exactly but, by proving whole
-shapes absent from a 256-pixel tile, executes a small fraction of that census
+shapes absent from a rectangle of 64 x 32 pixels, executes a small fraction of that census
 (profiles/), so the roof that binds it is the output store: `roofline.bound` is
 "hbm" with 3 B/pixel; the census figure is kept beside it as `valu_f64_census`.
 """
@@ -43,7 +43,7 @@ ALG_OPS_PER_PIXEL = 10241          # 10,239 unique non-constant 
 PEAK_F64_TOPS = 39.3               # MI355X f64 VALU, non-FMA instr/s: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 PEAK_PCIE_GBS = 63.0               # PCIe Gen5 x16 (MI355X_MICROARCH.md)
-BLOCK_ROWS = 64                    # rows are dealt to the ranks in blocks of this many (a multiple of the 8-row guard groups)
+BLOCK_ROWS = 64                    # rows are dealt to the ranks in blocks of this many (a multiple of the 32-row guard groups)
 
 _FIRST_RENDER = r'''
 import json, os, sys, time
@@ -357,7 +357,7 @@ def main():
                                              'frac': census_tops / PEAK_F64_TOPS, 'alg_ops_per_pixel': ALG_OPS_PER_PIXEL,
                                              'note': 'SURVEY 8(d) census of the scene DAG (10,241 f64 ops per pixel) / kernel '
                                                      'time; far above 1 because regions gated by a boolean that a y-only bound '
-                                                     'proves 0 over a 256-pixel tile are skipped, and half of what remains is '
+                                                     'proves 0 over a rectangle of 64 x 32 pixels are skipped, and half of what remains is '
                                                      'boolean algebra on lane masks (scalar unit)'},
                          'executed': executed},
             'end_to_end': e2e,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""tools/census_tiles.py — what a 64-pixel wavefront executes on chess @4096^2, row by row: tape ops by opcode and SKIP tests
-(guards per 8-row x 256-pixel rectangle, wave-level regions) taken / not taken, with the numpy tape evaluator of the test
-suite (CPU only).  DESIGN.md section 4.1 quotes it."""
+"""tools/census_tiles.py [GW GH] — what a 64-pixel wavefront executes on chess @4096^2, row by row: tape ops by opcode and SKIP
+tests (guards per rectangle of GW pixels x GH rows, default 64 x 32; wave-level regions) taken / not taken, with the numpy tape
+evaluator of the test suite (CPU only).  DESIGN.md section 4.1 quotes it."""
 import sys, collections, numpy as np
 sys.path[:0]=['/root/repo','/root/repo/tests']
 import maray_amd as M, tape_eval as T
@@ -11,16 +11,18 @@ s=M.Scene(data); s.rescale(4,4); tape=s.lower()
 consts,row_ops,pix_ops=tape.arrays(); info=tape.info
 NAMES={v:k for k,v in OP.items()}
 n_ynum = 292
+GW = int(sys.argv[1]) if len(sys.argv) > 2 else 64
+GH = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 def prof_row(y, w=4096):
-    # guards per rectangle of 8 rows x 256 px
-    g0 = (y//8)*8
+    # guards per rectangle of GH rows x GW px
+    g0 = (y//GH)*GH
     cnt=collections.Counter()
     per_wave=[]
-    for tx in range(0,w,256):
+    for tx in range(0,w,GW):
         ys=np.array([float(y)])
-        outs=T.run_section(row_ops,consts,info['n_row_slots'],None,ys,None,None,info['n_yvals'],True,w=w,span=(tx,min(w,tx+256)-1),yspan=(np.array([float(g0)]),np.array([float(g0+7)])))
+        outs=T.run_section(row_ops,consts,info['n_row_slots'],None,ys,None,None,info['n_yvals'],True,w=w,span=(tx,min(w,tx+GW)-1),yspan=(np.array([float(g0)]),np.array([float(g0+GH-1)])))
         yv=np.stack(outs,axis=-1)[0]
-        for x0 in range(tx,tx+256,64):
+        for x0 in range(tx,tx+GW,64):
             X=np.arange(x0,x0+64,dtype=np.float64); Y=np.full(64,float(y))
             yvb=np.broadcast_to(yv[None,:],(64,info['n_yvals']))
             c=run_count(pix_ops,consts,info['n_pix_slots'],X,Y,yvb)
