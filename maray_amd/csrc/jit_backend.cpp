@@ -21,6 +21,7 @@
 
 #include <sys/stat.h>
 #include <unistd.h>
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -41,6 +42,7 @@
 #include "host_pipe.hpp"
 #include "maray_hip.h"
 
+extern "C" const char maray_build_id[];          // _obj/build_id.cpp (Makefile): a hash of this library's sources
 extern "C" const char maray_embedded_device_math_h[];
 extern "C" const char maray_embedded_libm_h[];
 extern "C" const char maray_embedded_libm_tables_h[];
@@ -1462,31 +1464,103 @@ std::mutex g_code_mutex;
 std::map<std::string, std::shared_future<std::shared_ptr<const JitCode>>> g_code;
 std::vector<std::string> g_code_order;              // oldest first: the table keeps the 32 most recent programs (the rest live on disk)
 
-struct CodeKey { std::string hex, src_pix, src_rows; uint32_t n_row_chunks = 1, n_gjobs = 0; };
+// The code key names the code objects of a program: a hash of the two generated sources, the embedded headers and the
+// build options -- whatever changes the kernels changes it.  Generating the sources costs ~0.1 s for chess, so the key of
+// a program is remembered under a cheaper name: a hash of the program itself (constants, both sections), the generator
+// (MARAY_BUILD_ID: a hash of this library's sources, made by the Makefile), every MARAY_JIT_* knob of the environment and
+// the compiler's version -- in the process and, next to the code objects, in <cache>/<name>.key.
+struct CodeKey { std::string hex, src_pix, src_rows; uint32_t n_row_chunks = 1, n_gjobs = 0; bool have_src = false; };
+
+std::string hex128(uint64_t h1, uint64_t h2)
+{
+    char buf[40];
+    snprintf(buf, sizeof buf, "%016llx%016llx", (unsigned long long)h1, (unsigned long long)h2);
+    return buf;
+}
+
+std::string key_salt()
+{
+    int major = 0, minor = 0;
+    (void)hiprtcVersion(&major, &minor);          // a process that imported PyTorch first compiles with PyTorch's own hiprtc
+    return std::string(maray_version()) + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) +
+           "|" + JIT_OPTIONS + "|" + (getenv("MARAY_JIT_OPT") ? getenv("MARAY_JIT_OPT") : "");
+}
+
+std::string program_name(const maray_program &prog)
+{
+    std::string salt = key_salt() + "|" + maray_build_id;
+    std::vector<std::string> knobs;
+    for (char **e = environ; e && *e; e++) if (!strncmp(*e, "MARAY_JIT_", 10)) knobs.push_back(*e);
+    std::sort(knobs.begin(), knobs.end());
+    for (const std::string &kn : knobs) salt += "|" + kn;
+    const uint32_t counts[8] = {prog.version, prog.n_consts, prog.n_row_ops, prog.n_row_slots, prog.n_yvals, prog.n_pix_ops, prog.n_pix_slots, prog.n_app};
+    uint64_t h[2] = {0xcbf29ce484222325ull, 0x84222325cbf29ce4ull};
+    for (uint64_t &x : h) {
+        x = fnv1a(salt.data(), salt.size(), x);
+        x = fnv1a(counts, sizeof counts, x);
+        x = fnv1a(prog.consts, (size_t)prog.n_consts * sizeof(double), x);
+        x = fnv1a(prog.row_ops, (size_t)prog.n_row_ops * sizeof(uint64_t), x);
+        x = fnv1a(prog.pix_ops, (size_t)prog.n_pix_ops * sizeof(uint64_t), x);
+    }
+    return hex128(h[0], h[1]);
+}
+
+void key_sources(const maray_program &prog, CodeKey &k)
+{
+    if (k.have_src) return;
+    k.src_pix = jit_source(prog);
+    if (prog.n_row_ops) k.src_rows = jit_source_rows(prog, &k.n_row_chunks, &k.n_gjobs);
+    k.have_src = true;
+}
+
+std::mutex g_name_mutex;
+std::map<std::string, std::string> g_names;           // program name -> code key
 
 CodeKey code_key(const maray_program &prog)
 {
     CodeKey k;
-    k.src_pix = jit_source(prog);
-    if (prog.n_row_ops) k.src_rows = jit_source_rows(prog, &k.n_row_chunks, &k.n_gjobs);
-    int major = 0, minor = 0;
-    (void)hiprtcVersion(&major, &minor);          // a process that imported PyTorch first compiles with PyTorch's own hiprtc
-    const std::string salt = std::string(maray_version()) + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) +
-                             "|" + JIT_OPTIONS + "|" + (getenv("MARAY_JIT_OPT") ? getenv("MARAY_JIT_OPT") : "");
-    uint64_t h1 = fnv1a(salt.data(), salt.size(), 0xcbf29ce484222325ull), h2 = fnv1a(salt.data(), salt.size(), 0x84222325cbf29ce4ull);
-    for (const std::string *t : {&k.src_pix, &k.src_rows}) { h1 = fnv1a(t->data(), t->size() + 1, h1); h2 = fnv1a(t->data(), t->size() + 1, h2); }
-    for (const char *hd : {maray_embedded_device_math_h, maray_embedded_libm_h, maray_embedded_libm_tables_h}) { h1 = fnv1a(hd, strlen(hd), h1); h2 = fnv1a(hd, strlen(hd), h2); }
-    char buf[40];
-    snprintf(buf, sizeof buf, "%016llx%016llx", (unsigned long long)h1, (unsigned long long)h2);
-    k.hex = buf;
+    const std::string name = program_name(prog), dir = cache_dir();
+    {
+        std::lock_guard<std::mutex> lk(g_name_mutex);
+        auto it = g_names.find(name);
+        if (it != g_names.end()) { k.hex = it->second; return k; }
+    }
+    const std::string path = dir.empty() ? "" : dir + "/" + name + ".key";
+    if (!path.empty())
+        if (FILE *f = fopen(path.c_str(), "rb")) {
+            char buf[33] = {0};
+            const bool ok = fread(buf, 1, 32, f) == 32 && strspn(buf, "0123456789abcdef") == 32;
+            fclose(f);
+            if (ok) k.hex = buf;
+        }
+    if (k.hex.empty()) {
+        key_sources(prog, k);
+        const std::string salt = key_salt();
+        uint64_t h1 = fnv1a(salt.data(), salt.size(), 0xcbf29ce484222325ull), h2 = fnv1a(salt.data(), salt.size(), 0x84222325cbf29ce4ull);
+        for (const std::string *t : {&k.src_pix, &k.src_rows}) { h1 = fnv1a(t->data(), t->size() + 1, h1); h2 = fnv1a(t->data(), t->size() + 1, h2); }
+        for (const char *hd : {maray_embedded_device_math_h, maray_embedded_libm_h, maray_embedded_libm_tables_h}) { h1 = fnv1a(hd, strlen(hd), h1); h2 = fnv1a(hd, strlen(hd), h2); }
+        k.hex = hex128(h1, h2);
+        if (!path.empty()) {
+            mkdirs(dir);
+            const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+            if (FILE *f = fopen(tmp.c_str(), "wb")) {
+                const bool ok = fwrite(k.hex.data(), 1, 32, f) == 32;
+                if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());
+            }
+        }
+    }
+    std::lock_guard<std::mutex> lk(g_name_mutex);
+    if (g_names.size() > 256) g_names.clear();
+    g_names[name] = k.hex;
     return k;
 }
 
-std::shared_ptr<const JitCode> build_code(const maray_program &prog, const CodeKey &k)
+std::shared_ptr<const JitCode> build_code(const maray_program &prog, CodeKey &k)
 {
     auto c = std::make_shared<JitCode>();
     const std::string dir = cache_dir(), path = dir.empty() ? "" : dir + "/" + k.hex + ".mrco";
     if (!path.empty() && cache_read(path, *c)) { c->from_disk = true; return c; }
+    key_sources(prog, k);          // (a key that came from its cheaper name has no sources yet)
     std::string log;
     // Occupancy: the highest of 8 / 6 / 4 waves per SIMD (<= 64 / 80 / 128 VGPRs) whose build needs no scratch:
     // spilled VGPRs are HBM traffic.  MARAY_JIT_WAVES=<n> forces a build for n waves.
@@ -1519,7 +1593,7 @@ bool jit_code_is_cached(const maray_program &prog)
 
 std::shared_ptr<const JitCode> jit_code_for(const maray_program &prog)
 {
-    const CodeKey k = code_key(prog);
+    CodeKey k = code_key(prog);
     std::promise<std::shared_ptr<const JitCode>> mine;
     std::shared_future<std::shared_ptr<const JitCode>> fut;
     bool build = false;
@@ -1612,6 +1686,15 @@ struct JitBackend final : Backend {
 
     void init(int dev, const maray_program &prog, const maray_texture *tex, uint32_t n_tex) {
         device = dev;
+        // MARAY_TRACE_INIT=1: where the time of a context's creation goes (stderr)
+        const bool trace = getenv("MARAY_TRACE_INIT") && getenv("MARAY_TRACE_INIT")[0] == '1';
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!trace) return;
+            const auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "maray init: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+            t_last = now;
+        };
         HIP_TRY(hipSetDevice(dev));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
@@ -1626,9 +1709,12 @@ struct JitBackend final : Backend {
         k_row_block = jit_row_block();
         if (const char *e_ = getenv("MARAY_JIT_TILES")) if (atoi(e_) > 0) k_tiles = (unsigned)atoi(e_);
         if (const char *e_ = getenv("MARAY_JIT_BLOCKS_PER_CU")) if (atoi(e_) > 0) k_per_cu = (unsigned)atoi(e_);
+        lap("device");
         code = jit_code_for(prog);                       // built by the first context of the process, or read from the cache
+        lap("code objects");
         HIP_TRY(hipModuleLoadData(&mod, code->pix.data()));
         HIP_TRY(hipModuleGetFunction(&f_pix, mod, "maray_jit_pixels"));
+        lap("load PIXEL module");
         n_row_chunks = code->n_row_chunks; n_gjobs = code->n_gjobs;
         if (has_sin) slow = make_tape_backend(dev, prog, tex, n_tex, false);     // drains the tiles the pixel kernel defers; other programs never defer
         P = prog;
@@ -1640,9 +1726,11 @@ struct JitBackend final : Backend {
             if (n_gwords && !(getenv("MARAY_JIT_NO_ORDER") && getenv("MARAY_JIT_NO_ORDER")[0] == '1')) HIP_TRY(hipModuleGetFunction(&f_order, mod_rows, "maray_jit_order"));
             guard_rows = jit_guard_rows(prog);
             guard_sub = 256u / jit_guard_geom(prog).gw;
+            lap("load ROW module");
 
         }
         pipe.init(dev);
+        lap("host pipe");
         own_stream = pipe.compute_stream();
         HIP_TRY(hipEventCreateWithFlags(&handover, hipEventDisableTiming));
         HIP_TRY(hipStreamCreateWithFlags(&row_stream, hipStreamNonBlocking));
@@ -1661,6 +1749,7 @@ struct JitBackend final : Backend {
         }
         HIP_TRY(hipMalloc((void **)&d_tex, descs.size() * sizeof(DevTex)));
         HIP_TRY(hipMemcpy(d_tex, descs.data(), descs.size() * sizeof(DevTex), hipMemcpyHostToDevice));
+        lap("streams, events, textures");
     }
 
     template <typename T>

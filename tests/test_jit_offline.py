@@ -90,3 +90,43 @@ def test_random_scenes_build():
         build(tape)
         built += 1
     assert built >= 35
+
+
+def test_code_key_is_remembered_under_the_programs_name(chess_bytes, tmp_path, monkeypatch):
+    """The code key hashes the generated sources (0.1 s for chess); it is remembered under a hash of the program, the
+    library's build and the MARAY_JIT_* knobs, in the process and in <cache>/<name>.key.  A knob that changes the source
+    changes the key, one that does not (a launch-time knob) maps another name onto the same key; a cache directory that
+    cannot be written is not an error."""
+    import os
+    import time
+    monkeypatch.setenv('MARAY_CACHE_DIR', str(tmp_path))
+    tape = M.Scene(chess_bytes).lower()
+    t0 = time.perf_counter()
+    key = tape.jit_code_key
+    t_first = time.perf_counter() - t0
+    names = sorted(os.listdir(tmp_path))
+    assert len(key) == 32 and len(names) == 1 and names[0].endswith('.key') and open(tmp_path / names[0]).read() == key
+    t0 = time.perf_counter()
+    assert tape.jit_code_key == key
+    assert time.perf_counter() - t0 < t_first / 4                       # no source generation the second time
+    assert not tape.jit_code_cached                                     # nothing was built: there are no code objects yet
+    monkeypatch.setenv('MARAY_JIT_TILES', '3')                          # launch-time knob: same sources
+    assert tape.jit_code_key == key and len(os.listdir(tmp_path)) == 2
+    monkeypatch.setenv('MARAY_JIT_GUARD_W', '256')                      # changes the generated kernels
+    other = tape.jit_code_key
+    assert other != key and len(os.listdir(tmp_path)) == 3
+    monkeypatch.delenv('MARAY_JIT_TILES')
+    monkeypatch.delenv('MARAY_JIT_GUARD_W')
+    # a name file that is not a key is ignored and rewritten
+    open(tmp_path / names[0], 'w').write('not a key')
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path[:0] = [%r, %r]; import maray_amd as M; "
+            "print(M.Scene(open(%r, 'rb').read()).lower().jit_code_key)" % (os.path.dirname(here), here, os.path.join(here, 'golden', 'chess.maray')))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=dict(os.environ), timeout=300)
+    assert out.stdout.strip() == key, out.stderr[-500:]
+    assert open(tmp_path / names[0]).read() == key
+    monkeypatch.setenv('MARAY_CACHE_DIR', '/proc/no/such/dir')
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=dict(os.environ), timeout=300)
+    assert out.stdout.strip() == key, out.stderr[-500:]
