@@ -136,6 +136,7 @@ struct Emitter {
     bool out_guard_bits = false;                 // ROW-section OUT of a guard (index >= guard_first): OR its bit into `gacc`
     bool ktab = false;
     uint32_t min_region = 0;                    // PIXEL: wave-level SKIP ops over fewer ops than this are ignored
+    uint32_t min_region_row = 0;                // ROW: the same (a wavefront's lanes are 64 rows, or the 64 rectangles of a band of rows)
     // y values that are booleans (exactly +0.0 or 1.0 on every row: a Step of y-only arguments and what AND / OR / NOT make
     // of such): the PIXEL section reads them as lane masks (all lanes or none) from a scalar compare, so that min / max /
     // mul with them stay mask algebra.  Left as numbers they turn every shape they clip -- and then the whole OR tree of
@@ -226,7 +227,8 @@ struct Emitter {
                 const uint32_t gref = MARAY_INS_A(ins);
                 const bool row_guard = pixel && MARAY_REF_KIND(gref) == MARAY_K_YVAL;
                 if (row_guard && ignore_row_guards) continue;      // legal: an evaluator may ignore any SKIP op
-                if (!row_guard && pixel && min_region) {                   // a wave-level region too cheap to pay for its test and branch
+                const uint32_t min_region = pixel ? this->min_region : min_region_row;
+                if (!row_guard && min_region) {                            // a wave-level region too cheap to pay for its test and branch
                     // what the region's ops cost the vector unit, roughly in instructions: a gather, a libm body or a division
                     // is not "an op" (a 20-op region around a texture lookup is worth its branch)
                     uint32_t cost = 0;
@@ -620,6 +622,12 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
     const uint32_t n_ynum = numeric_yvals(P), n_gwords = jit_guard_words(P);
     const GuardPlan plan = jit_guard_plan(P);
     const GuardGeom geom = jit_guard_geom(P);
+    // wave-level SKIP ops of the ROW section: a wavefront's lanes are 64 rows, or the 64 rectangles of a band of rows, and
+    // agree on the sky only; a job is one wavefront's chain, and every short region it has to test and branch around
+    // lengthens it (chess, step minus pixel kernel in us, regions kept from 0 / 12 / 24 / 60 / 200 instructions / none:
+    // 7.2 / 6.9 / 6.3 / 6.8 / 8.3 / 8.3)
+    E.min_region_row = 24;
+    if (const char *e_ = getenv("MARAY_JIT_ROW_MIN_REGION")) E.min_region_row = (uint32_t)atoi(e_);
     const uint32_t n_gjobs = n_gwords ? (plan.n_pos + 7) / 8 : 0;                // 8 bits = one byte of a word per job
     if (n_gjobs_out) *n_gjobs_out = n_gjobs;
     // the interpreter (which drains deferred tiles from the same y-value table) does read the guard values
@@ -860,9 +868,9 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
          "                                                                    const unsigned long long *__restrict__ gbits, unsigned n_tx,\n"
          "                                                                    unsigned w, unsigned y0, unsigned n_yvals, unsigned tiles,\n"
          "                                                                    unsigned blk_rows, unsigned blk_stride, unsigned row_base, unsigned yrows,\n"
-         "                                                                    const unsigned *__restrict__ row_order, unsigned rows, unsigned strip_shift)\n{\n"
+         "                                                                    const unsigned *__restrict__ row_order, unsigned rows, unsigned strip_shift, unsigned swz)\n{\n"
          "    const unsigned mr_wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), mr_lane = threadIdx.x & 63u;\n"
-         "    (void)rows; (void)strip_shift;\n"
+         "    (void)rows; (void)strip_shift; (void)swz;\n"
          + std::string(persist ?
            "    // Persistent wavefronts: the grid fills the device once and every wavefront walks the (row, strip) items w, w + W,\n"
            "    // w + 2 W, ... of the launch, rows in launch order (dearest groups first): each wavefront meets every price band,\n"
@@ -873,7 +881,11 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
            "    const unsigned tile0 = (mr_item - mr_slot * mr_strips) * tiles;          // this item's strip of its row\n"
            "    const unsigned r = row_order ? row_order[mr_slot] : mr_slot;             // row of this launch; row_base + r = row of the whole call\n"
            : (coop ? "    const unsigned tile0 = blockIdx.x * tiles;                              // this block's strip of the row\n"
-                   : "    const unsigned tile0 = (blockIdx.x * 4u + mr_wv) * tiles;               // this wavefront's strip of the row\n")) +
+                   : "    // Workgroups go to the 8 XCDs round robin by their linear id, blockIdx.y * gridDim.x + blockIdx.x: with 2, 4 or 8\n"
+                     "    // blocks per row a column of the image would always meet the same XCDs, and a scene that is busier on one side\n"
+                     "    // would load them unevenly.  So a row's blocks take its strips rotated by the row (swz = gridDim.x - 1 when that\n"
+                     "    // is a power of two, else 0).\n"
+                     "    const unsigned tile0 = ((((blockIdx.x + blockIdx.y) & swz) | (blockIdx.x & ~swz)) * 4u + mr_wv) * tiles;               // this wavefront's strip of the row\n")) +
          (persist ? "" :
          "    if (tile0 >= n_tx) return;\n"
          "    const unsigned r = row_order ? row_order[blockIdx.y] : blockIdx.y;     // row of this launch (dearest groups of rows first); row_base + r = row of the whole call\n") +
@@ -1659,7 +1671,7 @@ struct JitBackend final : Backend {
     uint32_t n_row_chunks = 1, n_gwords = 0, n_gjobs = 0, guard_rows = 1, guard_sub = 1;       // guard_sub: guard rectangles per 256-pixel tile
     uint32_t n_cu = 256;
     // launch-time tuning knobs, read once when the context is created
-    bool k_overlap = false, k_coop = false, k_persist = false, wide_all = false;
+    bool k_overlap = false, k_coop = false, k_persist = false, wide_all = false, k_swz = true;
     unsigned k_row_block = 256, k_tiles = 0, k_per_cu = 7;
     uint32_t px = 4;                    // pixels per lane of the PIXEL kernel this context was built with
     bool has_sin = false;               // some Sin argument is not proven bounded: tiles may be deferred to `slow`
@@ -1706,6 +1718,7 @@ struct JitBackend final : Backend {
         k_coop = jit_coop(); k_persist = jit_persist();
         wide_all = jit_wide_general(prog);
         if (const char *e_ = getenv("MARAY_JIT_ROW_OVERLAP")) k_overlap = e_[0] == '1';
+        if (const char *e_ = getenv("MARAY_JIT_SWIZZLE")) k_swz = e_[0] != '0';
         k_row_block = jit_row_block();
         if (const char *e_ = getenv("MARAY_JIT_TILES")) if (atoi(e_) > 0) k_tiles = (unsigned)atoi(e_);
         if (const char *e_ = getenv("MARAY_JIT_BLOCKS_PER_CU")) if (atoi(e_) > 0) k_per_cu = (unsigned)atoi(e_);
@@ -1853,6 +1866,7 @@ struct JitBackend final : Backend {
             if (n_gwords && n_gwords <= jit_gw_inline_max()) tiles = std::min(tiles, 64u / (n_gwords * guard_sub));
             tiles = std::max(1u, std::min(tiles, n_tx));
             gx = coop ? (n_tx + tiles - 1) / tiles : (n_tx + 4 * tiles - 1) / (4 * tiles);
+            if (const char *e_ = getenv("MARAY_JIT_PAD_GRID")) if (atoi(e_) > 1) gx *= (unsigned)atoi(e_);      // measurement: blocks that exit at once
         } else {
             tiles = has_sin ? 1u : (unsigned)std::min<uint64_t>(std::min<uint64_t>(8, n_tx), std::max<uint64_t>(1, n_tiles / 4096));
             if (k_tiles && !has_sin) tiles = std::min(n_gwords > 12 ? 8u : 16u, k_tiles);      // (the kernel stages guard words for <= 16 / 8 tiles)
@@ -1874,7 +1888,8 @@ struct JitBackend final : Backend {
             const unsigned long long *gb = d_gbits;
             unsigned *fl = d_flags;
             const double *yv = d_yvals;
-            void *args[] = {&d8, &d64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles, &blk_rows, &blk_stride, &row_base, &yrows, &row_order, &rr, &shift};
+            unsigned swz = 0;
+            void *args[] = {&d8, &d64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles, &blk_rows, &blk_stride, &row_base, &yrows, &row_order, &rr, &shift, &swz};
             HIP_TRY(hipModuleLaunchKernel(f_pix, blocks, 1, 1, 256, 1, 1, 0, st, args, nullptr));
         } else
         for (uint32_t r0 = 0; r0 < rows_total; r0 += 65535) {          // gridDim.y limit
@@ -1886,7 +1901,9 @@ struct JitBackend final : Backend {
             unsigned ww = w, yy0 = y0, tile_base = r0 * (px == 4 ? n_tx : gx), row_base = r0, rr = rows, shift = 0xFFFFFFFFu;
             const unsigned long long *gb = d_gbits;              // indexed by the row of the whole call
             unsigned ntx = n_tx;
-            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles, &blk_rows, &blk_stride, &row_base, &yrows, &row_order, &rr, &shift};
+            // (the kernels of the other layouts take no `swz`: a trailing element of `args` they do not declare is not read)
+            unsigned swz = (px == 4 && !k_coop && k_swz && gx > 1 && (gx & (gx - 1)) == 0) ? gx - 1 : 0u;
+            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles, &blk_rows, &blk_stride, &row_base, &yrows, &row_order, &rr, &shift, &swz};
             HIP_TRY(hipModuleLaunchKernel(f_pix, gx, rows, 1, 256, 1, 1, 0, st, args, nullptr));
         }
         if (has_sin) slow->render_flagged(w, rb, d8, d64, st, d_flags, d_yvals);   // no-op unless a tile was deferred
