@@ -55,12 +55,15 @@ s.rescale(4, 4)
 tape = s.lower()
 M.device_count()                                   # HIP runtime initialisation is not part of the figure
 pin = M.PinnedRaster(4096, 4096)
+cached = tape.jit_code_cached                      # code objects of this program in MARAY_CACHE_DIR before the context exists
 t0 = time.perf_counter()
 ctx = M.Context(tape, backend=%(backend)d)
 t1 = time.perf_counter()
 ctx.render_rows_into(4096, 4096, 0, 4096, pin.array)
 t2 = time.perf_counter()
-print(json.dumps({'ctx_ms': (t1 - t0) * 1e3, 'frame_ms': (t2 - t1) * 1e3, 'cached': tape.jit_code_cached}))
+ctx.render_rows_into(4096, 4096, 0, 4096, pin.array)
+t3 = time.perf_counter()
+print(json.dumps({'ctx_ms': (t1 - t0) * 1e3, 'frame_ms': (t2 - t1) * 1e3, 'second_frame_ms': (t3 - t2) * 1e3, 'cached': cached}))
 '''
 
 
@@ -121,13 +124,21 @@ def main():
     layout = interleaved_layout(rank, n_gpus, h_total, BLOCK_ROWS)     # the same rows as one launch (None: ragged, block by block)
     rows_mine = sum(b - a for a, b in blocks)
 
-    # ---- cold start: a scratch cache directory, so that the first context below really builds its kernels -----------
+    # ---- first render of a fresh process: cold (scratch cache directories: hiprtc builds both kernels), warm (the code
+    # objects the cold one left), interpreter.  Processes of their own, without PyTorch: a process that imported PyTorch
+    # compiles with PyTorch's bundled hiprtc, another compiler version and so another code key than a plain one.
     cold = None
-    scratch = None
     if solo and not args.no_cold and args.backend in ('auto', 'jit') and args.scaling == 'weak':
         scratch = tempfile.mkdtemp(prefix='maray_bench_')
-        os.environ['MARAY_CACHE_DIR'] = os.path.join(scratch, 'maray')
-        os.environ['AMD_COMGR_CACHE_DIR'] = os.path.join(scratch, 'comgr')      # comgr keeps a cache of its own
+        env = {'MARAY_CACHE_DIR': os.path.join(scratch, 'maray'), 'AMD_COMGR_CACHE_DIR': os.path.join(scratch, 'comgr')}      # comgr keeps a cache of its own
+        cold = {'cold_cache': first_render(M.BACKEND_JIT, env)}
+        cold['cold_cache']['what'] = 'a fresh process, scratch MARAY_CACHE_DIR and comgr cache: hiprtc builds both kernels; frame = first 4096^2 frame into a pinned raster'
+        cold['warm_cache'] = first_render(M.BACKEND_JIT, env)
+        cold['warm_cache']['what'] = 'a fresh process, code objects read from MARAY_CACHE_DIR'
+        cold['interpreter'] = first_render(M.BACKEND_TAPE_SMEM, env)
+        cold['interpreter']['what'] = 'a fresh process, MARAY_BACKEND_TAPE_SMEM: no build; what MARAY_BACKEND_AUTO takes for a one-shot render'
+        import shutil
+        shutil.rmtree(scratch, ignore_errors=True)
 
     backends = {'tape': M.BACKEND_TAPE, 'tape-smem': M.BACKEND_TAPE_SMEM, 'jit': M.BACKEND_JIT}
     order = ['jit', 'tape-smem', 'tape'] if args.backend == 'auto' else [args.backend]
@@ -165,13 +176,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if scratch:
-        # the very first frame of a freshly built context, outputs in HBM (row order kernel and all one-time work included)
+    if cold is not None:
+        # this process: context creation (a build unless the default cache directory has the kernels) and the very first
+        # frame of the context, outputs in HBM (one-time work included)
         step()
         torch.cuda.synchronize()
         t_first = time.perf_counter()
-        cold = {'cold_cache': {'ctx_ms': (t_ctx1 - t_ctx0) * 1e3, 'frame_ms': (t_first - t_ctx1) * 1e3,
-                               'what': 'hiprtc builds both kernels (a scratch MARAY_CACHE_DIR and comgr cache), then the first frame'}}
+        cold['this_process'] = {'ctx_ms': (t_ctx1 - t_ctx0) * 1e3, 'frame_ms': (t_first - t_ctx1) * 1e3}
 
     for _ in range(args.warmup):
         step()
@@ -186,10 +197,15 @@ def main():
     px_per_step = w_img * h_total
     value = px_per_step * args.steps / dt / 1e6
 
-    # roofline of the dominant (pixel) kernel: HIP events on the launch stream, this rank's first block
+    # roofline of the dominant (pixel) kernel: HIP events on the launch stream, around the very launch a step issues (this
+    # rank's whole share; its first block when the share is ragged and goes block by block)
     a0, b0 = blocks[0]
-    k_ms = ctx.time_rows(w_img, h_total, a0, b0, d_rgb8=out8.data_ptr(), reps=max(3, min(args.steps, 10)))
-    px_launch = w_img * (b0 - a0)
+    if layout is not None:
+        k_ms = ctx.time_blocks(w_img, h_total, *layout, d_rgb8=out8.data_ptr(), reps=max(3, min(args.steps, 10)))
+        px_launch = w_img * rows_mine
+    else:
+        k_ms = ctx.time_rows(w_img, h_total, a0, b0, d_rgb8=out8.data_ptr(), reps=max(3, min(args.steps, 10)))
+        px_launch = w_img * (b0 - a0)
     census_tops = ALG_OPS_PER_PIXEL * px_launch / (k_ms * 1e-3) / 1e12
     hbm_gbs = (px_launch * 3) / (k_ms * 1e-3) / 1e9
 
@@ -258,16 +274,6 @@ def main():
             e2e['gen_to_image_what'] = ('maray_gen_to_image, whole call: lowering + context (code objects from the process cache) + '
                                         'render + DMA; the pageable raster is registered (pinned) for the call')
         pin.close()
-
-    # ---- warm-cache and interpreter first renders, each in a fresh process ----------------------------------------
-    if cold is not None:
-        env = {'MARAY_CACHE_DIR': os.environ['MARAY_CACHE_DIR'], 'AMD_COMGR_CACHE_DIR': os.environ['AMD_COMGR_CACHE_DIR']}
-        cold['warm_cache'] = first_render(M.BACKEND_JIT, env)
-        cold['warm_cache']['what'] = 'a fresh process, code objects read from MARAY_CACHE_DIR; frame = first 4096^2 frame into a pinned raster'
-        cold['interpreter'] = first_render(M.BACKEND_TAPE_SMEM, env)
-        cold['interpreter']['what'] = 'a fresh process, MARAY_BACKEND_TAPE_SMEM: no build; what MARAY_BACKEND_AUTO takes for a one-shot render'
-        import shutil
-        shutil.rmtree(scratch, ignore_errors=True)
 
     # HBM traffic per launch from the committed PMC profile of this very command (FETCH_SIZE x2 per the gfx950
     # correction of MI355X_MICROARCH.md + WRITE_SIZE); bench.py cannot collect PMC counters itself.  The profile names

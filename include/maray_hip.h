@@ -198,6 +198,9 @@ int maray_hip_render_blocks_device(maray_ctx *c, uint32_t w, uint32_t h, uint32_
  * the launch stream; returns the average milliseconds per launch. */
 int maray_hip_time_rows(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1,
                         void *d_rgb8, void *d_rgb64, int reps, float *ms_avg);
+/* The same for the launch maray_hip_render_blocks_device issues (one rank's interleaved share of an image). */
+int maray_hip_time_blocks(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uint32_t block_rows, uint32_t block_stride,
+                          uint32_t n_blocks, void *d_rgb8, void *d_rgb64, int reps, float *ms_avg);
 /* The part of a program's ROW section that y values [first_out, first_out + n_out) depend on, as the evaluators cut
  * it to run parts of the section side by side or per rectangle of pixels: a tape of its own (NOPs removed, SKIP
  * regions kept, value slots renumbered by liveness; *n_slots_out = slots it uses).  Free *ops_out with maray_free. */

@@ -110,6 +110,7 @@ def lib():
         'maray_hip_render_rows_device': (C.c_int, [vp, u32, u32, u32, u32, vp, vp, vp]),
         'maray_hip_render_blocks_device': (C.c_int, [vp, u32, u32, u32, u32, u32, u32, vp, vp, vp]),
         'maray_hip_time_rows': (C.c_int, [vp, u32, u32, u32, u32, vp, vp, C.c_int, C.POINTER(C.c_float)]),
+        'maray_hip_time_blocks': (C.c_int, [vp, u32, u32, u32, u32, u32, u32, vp, vp, C.c_int, C.POINTER(C.c_float)]),
         'maray_hip_kernel_name': (C.c_char_p, [vp]),
         'maray_jit_code_key': (C.c_int, [C.POINTER(Program), C.c_char_p]),
         'maray_jit_code_cached': (C.c_int, [C.POINTER(Program), C.POINTER(C.c_int)]),
@@ -357,6 +358,13 @@ class Context:
     def time_rows(self, w, h, y0, y1, d_rgb8=0, d_rgb64=0, reps=5):
         ms = C.c_float()
         _check(lib().maray_hip_time_rows(self._h, w, h, y0, y1, d_rgb8 or None, d_rgb64 or None, reps, C.byref(ms)))
+        return ms.value
+
+    def time_blocks(self, w, h, y0, block_rows, block_stride, n_blocks, d_rgb8=0, d_rgb64=0, reps=5):
+        """time_rows for the launch render_blocks_device issues."""
+        ms = C.c_float()
+        _check(lib().maray_hip_time_blocks(self._h, w, h, y0, block_rows, block_stride, n_blocks, d_rgb8 or None, d_rgb64 or None,
+                                           reps, C.byref(ms)))
         return ms.value
 
     @property

@@ -459,7 +459,21 @@ int maray_hip_time_rows(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uint3
         REQUIRE(c && c->backend && ms_avg, "null argument");
         check_rows(w, h, y0, y1);
         REQUIRE(y1 > y0 && w > 0 && reps > 0, "empty launch");
-        *ms_avg = c->backend->time_rows(w, h, y0, y1, d_rgb8, d_rgb64, reps);
+        *ms_avg = c->backend->time_rows(w, h, RowBlocks::range(y0, y1), d_rgb8, d_rgb64, reps);
+    });
+}
+
+int maray_hip_time_blocks(maray_ctx *c, uint32_t w, uint32_t h, uint32_t y0, uint32_t block_rows, uint32_t block_stride,
+                          uint32_t n_blocks, void *d_rgb8, void *d_rgb64, int reps, float *ms_avg)
+{
+    return guard([&] {
+        REQUIRE(c && c->backend && ms_avg, "null argument");
+        REQUIRE(n_blocks > 0 && block_rows > 0 && w > 0 && reps > 0, "empty launch");
+        REQUIRE(n_blocks == 1 || block_stride >= block_rows, "row blocks overlap: block_stride < block_rows");
+        const uint64_t last = (uint64_t)y0 + (uint64_t)(n_blocks - 1) * block_stride + block_rows;
+        REQUIRE(last <= 0xFFFFFFFFull && (uint64_t)n_blocks * block_rows <= 0xFFFFFFFFull, "row blocks out of range");
+        check_rows(w, h, y0, (uint32_t)last);
+        *ms_avg = c->backend->time_rows(w, h, RowBlocks{y0, n_blocks * block_rows, block_rows, n_blocks == 1 ? 0u : block_stride}, d_rgb8, d_rgb64, reps);
     });
 }
 

@@ -33,7 +33,7 @@ struct Backend {
     virtual void render_host_tiles(uint32_t w, uint32_t h, const std::vector<RowTile> &tiles, uint32_t row0, uint8_t *rgb8, double *rgb64,
                                    const std::function<void(uint32_t, uint32_t)> &done) = 0;
     // average ms per launch of the pixel kernel, HIP events on the launch stream
-    virtual float time_rows(uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, void *d8, void *d64, int reps) = 0;
+    virtual float time_rows(uint32_t w, uint32_t h, const RowBlocks &rb, void *d8, void *d64, int reps) = 0;
     virtual const char *kernel_name() const = 0;
     // Tape interpreter only: re-evaluate the 256-pixel tiles of the device work list
     // {count, tile, tile, ...} (tile = row_in_launch * ceil(w/256) + x/256), reading the row

@@ -1925,18 +1925,18 @@ struct JitBackend final : Backend {
                  [&](const RowBlocks &rb, unsigned char *d8, double *d64, hipStream_t st) { launch(w, rb, d8, d64, st, true); }, done);
     }
 
-    float time_rows(uint32_t w, uint32_t, uint32_t y0, uint32_t y1, void *d8, void *d64, int reps) override {
+    float time_rows(uint32_t w, uint32_t, const RowBlocks &rb, void *d8, void *d64, int reps) override {
         HIP_TRY(hipSetDevice(device));
-        const size_t n = (size_t)(y1 - y0) * w * 3;
+        const size_t n = (size_t)rb.n_rows * w * 3;
         unsigned char *p8 = (unsigned char *)d8;
         double *p64 = (double *)d64;
         if (!p8 && !p64) { ensure(d_rgb8, rgb8_cap, n); p8 = d_rgb8; }
-        launch(w, RowBlocks::range(y0, y1), p8, p64, own_stream, true);
-        launch(w, RowBlocks::range(y0, y1), p8, p64, own_stream, true);          // a geometry's second launch computes its row order
+        launch(w, rb, p8, p64, own_stream, true);
+        launch(w, rb, p8, p64, own_stream, true);          // a geometry's second launch computes its row order
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, own_stream));
-        for (int i = 0; i < reps; i++) launch(w, RowBlocks::range(y0, y1), p8, p64, own_stream, false);
+        for (int i = 0; i < reps; i++) launch(w, rb, p8, p64, own_stream, false);
         HIP_TRY(hipEventRecord(e1, own_stream));
         HIP_TRY(hipEventSynchronize(e1));
         float ms = 0.f;
