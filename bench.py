@@ -229,8 +229,8 @@ def main():
     e2e = None
     if not args.no_e2e:
         tiles = []
-        for a, b in blocks:                     # this rank's rows, cut into tiles of <= ~16 MiB of raster
-            step_rows = max(8, ((16 << 20) // (w_img * 3)) // 8 * 8)
+        for a, b in blocks:                     # this rank's rows, cut into tiles of <= ~24 MiB of raster (host_pipe.cpp's own choice)
+            step_rows = max(32, ((24 << 20) // (w_img * 3)) // 32 * 32)
             tiles += [(y, min(b, y + step_rows)) for y in range(a, b, step_rows)]
         pin = M.PinnedRaster(h_total, w_img)
         ctx.render_tiles(w_img, h_total, tiles, pin.array)          # warm: staging buffers allocated

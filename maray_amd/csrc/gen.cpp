@@ -112,13 +112,15 @@ extern "C" int maray_gen_to_image(const maray_scene *s, const maray_texture *tex
     if (n_dev_avail > 0 && n_dev > (uint32_t)n_dev_avail && !wrap)
         return fail_with(MARAY_E_NO_DEVICE, "asked for " + std::to_string(n_dev) + " devices, " + std::to_string(n_dev_avail) + " visible");
     if (n_dev > (h + 7) / 8) n_dev = (h + 7) / 8;
-    // Row tiles: ~16 MiB of raster each (the DMA engine's rate; the first copy starts early), but at least four per
-    // device, dealt round-robin: the cost of a row depends on what it shows (the kernels skip work tile by tile), so
-    // contiguous bands would leave the device with the busiest band behind.  Multiples of 8 rows (guard groups).
+    // Row tiles: ~24 MiB of raster each (the DMA engine's rate; the first copy starts early; host_pipe.cpp), but at least
+    // four per device, dealt round-robin: the cost of a row depends on what it shows (the kernels skip work tile by tile),
+    // so contiguous bands would leave the device with the busiest band behind.  Multiples of 32 rows (guard groups) where
+    // the image has that many.
     uint32_t tile_rows = opts && opts->tile_rows ? opts->tile_rows : 0;
     if (!tile_rows) {
-        const uint64_t by_bytes = std::max<uint64_t>(8, (((uint64_t)16 << 20) / ((uint64_t)w * 3)) / 8 * 8);
-        const uint64_t by_share = std::max<uint64_t>(8, ((uint64_t)h / (4ull * n_dev) + 7) / 8 * 8);
+        auto whole_groups = [](uint64_t r) { return r >= 32 ? r / 32 * 32 : std::max<uint64_t>(8, r / 8 * 8); };
+        const uint64_t by_bytes = whole_groups(((uint64_t)24 << 20) / ((uint64_t)w * 3));
+        const uint64_t by_share = whole_groups(((uint64_t)h / (4ull * n_dev) + 7));
         tile_rows = (uint32_t)std::min(by_bytes, n_dev > 1 ? by_share : by_bytes);
     }
     std::vector<std::vector<uint32_t>> share(n_dev);          // per device: y0, y1 pairs
