@@ -21,6 +21,10 @@
 
 #include <sys/stat.h>
 #include <unistd.h>
+#include <spawn.h>
+#include <dlfcn.h>
+#include <sys/wait.h>
+#include <cerrno>
 #include <chrono>
 
 #include <algorithm>
@@ -1567,6 +1571,87 @@ CodeKey code_key(const maray_program &prog)
     return k;
 }
 
+// ---- out-of-process builds ---------------------------------------------------------------------------------------
+// hiprtc serialises compiles inside a process (two threads: 7.9 s either way for chess, measured), and an LLVM abort
+// inside it takes the process down.  So a program's two modules are built by two helper processes side by side
+// (maray_jitc, next to this library; it dlopens the very hiprtc this process has loaded -- the compiler's version is
+// part of the code key): chess cold 2.6 -> 1.6 s.  MARAY_JIT_HELPER=0, a missing helper or one that dies: the module is
+// compiled in-process as before.  A source that does not compile is an error either way, with the compiler's log.
+std::string self_dir()
+{
+    Dl_info info;
+    if (!dladdr((const void *)&maray_build_id, &info) || !info.dli_fname) return "";
+    const std::string p = info.dli_fname;
+    const size_t at = p.rfind('/');
+    return at == std::string::npos ? "." : p.substr(0, at);
+}
+
+std::string hiprtc_path()
+{
+    Dl_info info;
+    if (!dladdr((const void *)&hiprtcCompileProgram, &info) || !info.dli_fname) return "";
+    return info.dli_fname;
+}
+
+struct HelperJob {
+    pid_t pid = -1;
+    std::string src_path, out_path;
+};
+
+bool read_file(const std::string &path, std::vector<char> &out)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char buf[1 << 16];
+    out.clear();
+    for (size_t n; (n = fread(buf, 1, sizeof buf, f)) > 0;) out.insert(out.end(), buf, buf + n);
+    fclose(f);
+    return true;
+}
+
+// starts the helper on `src`; pid stays -1 when it cannot be started
+HelperJob helper_start(const std::string &helper, const std::string &rtc, const std::string &src, const char *tag)
+{
+    HelperJob j;
+    const char *tmp = getenv("TMPDIR");
+    char path[512];
+    snprintf(path, sizeof path, "%s/maray_jit_%ld_%s_XXXXXX", (tmp && tmp[0]) ? tmp : "/tmp", (long)getpid(), tag);
+    const int fd = mkstemp(path);
+    if (fd < 0) return j;
+    const bool ok = write(fd, src.data(), src.size()) == (ssize_t)src.size();
+    close(fd);
+    j.src_path = path;
+    j.out_path = j.src_path + ".out";
+    if (!ok) return j;
+    const char *olevel = getenv("MARAY_JIT_OPT");
+    std::vector<char *> argv = {(char *)helper.c_str(), (char *)rtc.c_str(), (char *)j.src_path.c_str(), (char *)j.out_path.c_str()};
+    if (olevel && olevel[0] == '-') argv.push_back((char *)olevel);
+    argv.push_back(nullptr);
+    pid_t pid = -1;
+    if (posix_spawn(&pid, helper.c_str(), nullptr, nullptr, argv.data(), environ) == 0) j.pid = pid;
+    return j;
+}
+
+// 0: `code` holds the code object; 3: `log` holds the compiler's errors; else: the helper failed
+int helper_finish(HelperJob &j, std::vector<char> &code, std::string &log)
+{
+    int rc = -1;
+    if (j.pid > 0) {
+        int status = 0;
+        pid_t r;
+        do r = waitpid(j.pid, &status, 0); while (r < 0 && errno == EINTR);
+        if (r == j.pid && WIFEXITED(status)) rc = WEXITSTATUS(status);
+        std::vector<char> out;
+        if ((rc == 0 || rc == 3) && read_file(j.out_path, out)) {
+            if (rc == 0) code.swap(out); else log.assign(out.begin(), out.end());
+        } else if (rc == 0 || rc == 3) rc = -1;
+        if (rc == 0 && (code.size() < 64 || memcmp(code.data(), "\177ELF", 4) != 0)) rc = -1;
+    }
+    if (!j.src_path.empty()) (void)unlink(j.src_path.c_str());
+    if (!j.out_path.empty()) (void)unlink(j.out_path.c_str());
+    return rc;
+}
+
 std::shared_ptr<const JitCode> build_code(const maray_program &prog, CodeKey &k)
 {
     auto c = std::make_shared<JitCode>();
@@ -1574,15 +1659,30 @@ std::shared_ptr<const JitCode> build_code(const maray_program &prog, CodeKey &k)
     if (!path.empty() && cache_read(path, *c)) { c->from_disk = true; return c; }
     key_sources(prog, k);          // (a key that came from its cheaper name has no sources yet)
     std::string log;
+    // both modules in helper processes, side by side
+    bool have_pix = false, have_rows = false;
+    {
+        const char *e = getenv("MARAY_JIT_HELPER");
+        const std::string helper = self_dir() + "/maray_jitc", rtc = hiprtc_path();
+        if (!(e && e[0] == '0') && !rtc.empty() && access(helper.c_str(), X_OK) == 0) {
+            HelperJob jp = helper_start(helper, rtc, k.src_pix, "pix"), jr;
+            if (prog.n_row_ops) jr = helper_start(helper, rtc, k.src_rows, "rows");
+            std::string lp, lr;
+            const int rp = helper_finish(jp, c->pix, lp), rr = prog.n_row_ops ? helper_finish(jr, c->rows, lr) : -1;
+            if (rp == 3) throw Error{MARAY_E_HIP, "hiprtcCompileProgram (maray_jitc): the PIXEL kernel does not compile\n" + lp};
+            if (rr == 3) throw Error{MARAY_E_HIP, "hiprtcCompileProgram (maray_jitc): the ROW kernel does not compile\n" + lr};
+            have_pix = rp == 0; have_rows = rr == 0;
+        }
+    }
     // Occupancy: the highest of 8 / 6 / 4 waves per SIMD (<= 64 / 80 / 128 VGPRs) whose build needs no scratch:
     // spilled VGPRs are HBM traffic.  MARAY_JIT_WAVES=<n> forces a build for n waves.
     const int ladder[] = {jit_px() == 4 ? 6 : 8, jit_px() == 4 ? 4 : 6, jit_px() == 4 ? 2 : 4};
     for (int i = 0; i < 3; i++) {
-        jit_compile(i == 0 ? k.src_pix : jit_source(prog, ladder[i]), c->pix, log);
+        if (!(i == 0 && have_pix)) jit_compile(i == 0 ? k.src_pix : jit_source(prog, ladder[i]), c->pix, log);
         c->waves = ladder[i];
         if (code_meta_uint(c->pix, ".private_segment_fixed_size") <= 0 || getenv("MARAY_JIT_WAVES")) break;
     }
-    if (prog.n_row_ops) jit_compile(k.src_rows, c->rows, log);
+    if (prog.n_row_ops && !have_rows) jit_compile(k.src_rows, c->rows, log);
     c->n_row_chunks = k.n_row_chunks; c->n_gjobs = k.n_gjobs;
     if (!path.empty()) cache_write(dir, path, *c);
     return c;

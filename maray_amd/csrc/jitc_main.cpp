@@ -1,0 +1,77 @@
+// maray_jitc HIPRTC_LIB SOURCE OUT [-Ox] — compiles one generated kernel source to a gfx950 code object with the hiprtc
+// library the caller names (the one the calling process has loaded: its version is part of the code key), in a process of
+// its own: libmaray_hip.so starts one per module so that the PIXEL and the ROW kernels of a program build side by side
+// (hiprtc serialises compiles inside a process), and an LLVM abort ends this process, not the caller's.
+// Exit status 0: OUT holds the code object; 3: the source does not compile, OUT holds the log; anything else: the
+// helper itself failed (the caller then compiles in-process).
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" const char maray_embedded_device_math_h[];
+extern "C" const char maray_embedded_libm_h[];
+extern "C" const char maray_embedded_libm_tables_h[];
+
+namespace {
+
+typedef struct _hiprtcProgram *hiprtcProgram;
+typedef int (*create_fn)(hiprtcProgram *, const char *, const char *, int, const char **, const char **);
+typedef int (*compile_fn)(hiprtcProgram, int, const char **);
+typedef int (*size_fn)(hiprtcProgram, size_t *);
+typedef int (*get_fn)(hiprtcProgram, char *);
+typedef int (*destroy_fn)(hiprtcProgram *);
+
+bool write_file(const char *path, const char *data, size_t n)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return false;
+    const bool ok = fwrite(data, 1, n, f) == n;
+    return fclose(f) == 0 && ok;
+}
+
+}   // namespace
+
+int main(int argc, char **argv)
+{
+    if (argc < 4) { fprintf(stderr, "usage: maray_jitc HIPRTC_LIB SOURCE OUT [-Ox]\n"); return 2; }
+    void *lib = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { fprintf(stderr, "maray_jitc: %s\n", dlerror()); return 4; }
+    const create_fn create = (create_fn)dlsym(lib, "hiprtcCreateProgram");
+    const compile_fn compile = (compile_fn)dlsym(lib, "hiprtcCompileProgram");
+    const size_fn log_size = (size_fn)dlsym(lib, "hiprtcGetProgramLogSize"), code_size = (size_fn)dlsym(lib, "hiprtcGetCodeSize");
+    const get_fn get_log = (get_fn)dlsym(lib, "hiprtcGetProgramLog"), get_code = (get_fn)dlsym(lib, "hiprtcGetCode");
+    const destroy_fn destroy = (destroy_fn)dlsym(lib, "hiprtcDestroyProgram");
+    if (!create || !compile || !log_size || !code_size || !get_log || !get_code || !destroy) { fprintf(stderr, "maray_jitc: %s is not a hiprtc\n", argv[1]); return 4; }
+    std::string src;
+    {
+        FILE *f = fopen(argv[2], "rb");
+        if (!f) { perror(argv[2]); return 5; }
+        char buf[1 << 16];
+        for (size_t n; (n = fread(buf, 1, sizeof buf, f)) > 0;) src.append(buf, n);
+        fclose(f);
+    }
+    const char *headers[] = {maray_embedded_device_math_h, maray_embedded_libm_h, maray_embedded_libm_tables_h};
+    const char *names[] = {"device_math.h", "maray_libm.h", "maray_libm_tables.h"};
+    hiprtcProgram prog;
+    if (create(&prog, src.c_str(), "maray_jit.hip", 3, headers, names) != 0) return 6;
+    const char *olevel = argc > 4 && argv[4][0] == '-' ? argv[4] : "-O3";
+    const char *opts[] = {"--offload-arch=gfx950", olevel, "-ffp-contract=off", "-fno-fast-math", "-std=c++17"};       // = jit_compile (jit_backend.cpp)
+    const int rc = compile(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+    if (rc != 0) {
+        size_t ln = 0;
+        log_size(prog, &ln);
+        std::string log(ln, '\0');
+        if (ln) get_log(prog, &log[0]);
+        write_file(argv[3], log.data(), log.size());
+        return 3;
+    }
+    size_t n = 0;
+    if (code_size(prog, &n) != 0) return 6;
+    std::vector<char> code(n);
+    if (get_code(prog, code.data()) != 0) return 6;
+    destroy(&prog);
+    return write_file(argv[3], code.data(), code.size()) ? 0 : 7;
+}

@@ -130,3 +130,28 @@ def test_code_key_is_remembered_under_the_programs_name(chess_bytes, tmp_path, m
     monkeypatch.setenv('MARAY_CACHE_DIR', '/proc/no/such/dir')
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=dict(os.environ), timeout=300)
     assert out.stdout.strip() == key, out.stderr[-500:]
+
+
+def test_helper_processes_build_what_the_process_itself_builds(monkeypatch, tmp_path):
+    """The two modules of a program are built by two maray_jitc processes side by side (hiprtc serialises compiles inside
+    a process); MARAY_JIT_HELPER=0 compiles in-process.  Same compiler, same options: the same code objects.  A source
+    that does not compile comes back as MARAY_E_HIP with the compiler's log either way."""
+    import hashlib
+    monkeypatch.setenv('AMD_COMGR_CACHE', '0')
+    tape = M.Scene(encode((64, 64), scenes.all_ops(64, 64))).lower()
+    digests = []
+    for helper in ('1', '0'):
+        monkeypatch.setenv('MARAY_JIT_HELPER', helper)
+        monkeypatch.setenv('MARAY_CACHE_DIR', str(tmp_path / ('cache' + helper)))
+        _, blob = build(tape)
+        assert tape.jit_code_cached
+        digests.append(hashlib.sha256(blob).hexdigest())
+    assert digests[0] == digests[1]
+    monkeypatch.setenv('MARAY_JIT_OPT', '-Onotanoption')
+    for helper in ('1', '0'):
+        monkeypatch.setenv('MARAY_JIT_HELPER', helper)
+        monkeypatch.setenv('MARAY_CACHE_DIR', str(tmp_path / ('bad' + helper)))
+        L = M.lib()
+        code, n = C.c_void_p(), C.c_size_t()
+        assert L.maray_jit_build(C.byref(tape.program), C.byref(code), C.byref(n)) == -9          # MARAY_E_HIP
+        assert b'notanoption' in L.maray_last_error()
