@@ -328,8 +328,9 @@ int maray_hip_ctx_create(int device, const maray_program *prog, const maray_text
         case MARAY_BACKEND_JIT: b = make_jit_backend(device, *prog, tex, n_tex); break;
         case MARAY_BACKEND_AUTO: {
             // One-shot economics.  The specialised kernels render a frame tens of times faster than the interpreter, but
-            // hiprtc needs seconds to build them (chess: 10 k pixel + 17 k row ops -> 8 s; a 49 k-op scene took 6.5 min),
-            // the interpreter needs none.  So: take them when the code objects are already in the cache, or when the
+            // hiprtc needs seconds to build them (chess: 9 k pixel + 17 k row ops -> 1.6 s with the two modules built side
+            // by side; 1,000 triangles, 36 k + 37 k ops -> 15-20 s; before the lowering privatised shared values a 49 k-op
+            // scene took 6.5 min), the interpreter needs none.  So: take them when the code objects are already in the cache, or when the
             // caller says how much it will render (hint_mpixels) and the interpreter would need longer for that than
             // the build takes, or when it does not say (a context kept for many frames).  Estimates, measured on chess
             // and the triangle soups: build 0.5 s + 0.4 ms per pixel op + 0.24 ms per row op;
