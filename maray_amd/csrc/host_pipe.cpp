@@ -64,7 +64,8 @@ void HostPipe::init(int dev)
     device = dev;
     HIP_TRY(hipSetDevice(dev));
     HIP_TRY(hipStreamCreateWithFlags(&compute, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+    // (the copy stream is created by the first run(): a stream costs a context several milliseconds, and one that only
+    // ever renders into device buffers never copies)
     for (int s = 0; s < SLOTS; s++) {
         HIP_TRY(hipEventCreateWithFlags(&kernels_done[s], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&copy_done[s], hipEventDisableTiming));
@@ -93,6 +94,7 @@ void HostPipe::run(uint32_t w, const std::vector<RowTile> &tiles, uint32_t row0,
 {
     if (tiles.empty() || !w || (!rgb8 && !rgb64)) return;
     HIP_TRY(hipSetDevice(device));
+    if (!copy) HIP_TRY(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
     size_t max_px = 0;
     uint32_t lo = 0xFFFFFFFFu, hi = 0;
     for (const RowTile &t : tiles) {
@@ -159,7 +161,7 @@ void HostPipe::run(uint32_t w, const std::vector<RowTile> &tiles, uint32_t row0,
     } catch (...) {
         // nothing may still be writing the caller's raster or the ring when this call returns
         (void)hipStreamSynchronize(compute);
-        (void)hipStreamSynchronize(copy);
+        if (copy) (void)hipStreamSynchronize(copy);
         throw;
     }
 }

@@ -1846,10 +1846,12 @@ struct JitBackend final : Backend {
         lap("host pipe");
         own_stream = pipe.compute_stream();
         HIP_TRY(hipEventCreateWithFlags(&handover, hipEventDisableTiming));
-        HIP_TRY(hipStreamCreateWithFlags(&row_stream, hipStreamNonBlocking));
-        for (int b = 0; b < 2; b++) {
-            HIP_TRY(hipEventCreateWithFlags(&row_done[b], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&pix_done[b], hipEventDisableTiming));
+        if (k_overlap) {                                  // (a stream costs a context several milliseconds: only when it is used)
+            HIP_TRY(hipStreamCreateWithFlags(&row_stream, hipStreamNonBlocking));
+            for (int b = 0; b < 2; b++) {
+                HIP_TRY(hipEventCreateWithFlags(&row_done[b], hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&pix_done[b], hipEventDisableTiming));
+            }
         }
         std::vector<DevTex> descs(n_tex ? n_tex : 1);
         for (uint32_t i = 0; i < n_tex; i++) {
