@@ -300,9 +300,13 @@ struct Emitter {
                 bool declared = false;
                 for (const Open &o : open) if (o.end == end) { declared = true; typed_bool = o.as_bool; }
                 if (!declared) out += typed_bool ? "    " + tm + " b" + std::string(name) + ";\n" : "    " + td + " " + std::string(name) + ";\n";
-                // regions are entered rarely (chess: 2-20 %): mark them unlikely so that the block placement keeps the
-                // skip path as the fall-through and moves the region bodies out of line (taken jumps stall on instruction fetch)
-                out += "    if (__builtin_expect(" + cond + ", 0)) {\n";
+                // A region behind a rectangle guard is entered rarely (chess: 4 of the 15 a pass tests): unlikely, so that the block
+                // placement keeps the skip path as the fall-through and moves the bodies out of line (taken jumps stall on
+                // instruction fetch).  A wave-level region of the PIXEL section sits inside a shape whose guard let the wavefront
+                // in, and is entered nine times in ten (18 of 20 per pass): likely (board crop 82.3 -> 81.6 us; MARAY_JIT_EXPECT=0:
+                // every region unlikely, as it was).
+                const bool expect_wave = !(getenv("MARAY_JIT_EXPECT") && getenv("MARAY_JIT_EXPECT")[0] == '0');
+                out += "    if (__builtin_expect(" + cond + (expect_wave && pixel && !row_guard ? ", 1)) {\n" : ", 0)) {\n");
                 open.push_back(Open{end, typed_bool, nz, next_scope++});
                 ktab_block.clear();
                 continue;
