@@ -201,10 +201,10 @@ def main():
     # rank's whole share; its first block when the share is ragged and goes block by block)
     a0, b0 = blocks[0]
     if layout is not None:
-        k_ms = ctx.time_blocks(w_img, h_total, *layout, d_rgb8=out8.data_ptr(), reps=max(3, min(args.steps, 10)))
+        k_ms = ctx.time_blocks(w_img, h_total, *layout, d_rgb8=out8.data_ptr(), reps=max(10, min(args.steps, 50)))
         px_launch = w_img * rows_mine
     else:
-        k_ms = ctx.time_rows(w_img, h_total, a0, b0, d_rgb8=out8.data_ptr(), reps=max(3, min(args.steps, 10)))
+        k_ms = ctx.time_rows(w_img, h_total, a0, b0, d_rgb8=out8.data_ptr(), reps=max(10, min(args.steps, 50)))
         px_launch = w_img * (b0 - a0)
     census_tops = ALG_OPS_PER_PIXEL * px_launch / (k_ms * 1e-3) / 1e12
     hbm_gbs = (px_launch * 3) / (k_ms * 1e-3) / 1e9
