@@ -50,7 +50,7 @@ struct KArgs {
     uint32_t w, y0, rows;      // image width, first row, row count of this launch
     uint32_t blk_rows, blk_stride;   // launch row r is image row y0 + (r / blk_rows) * blk_stride + r % blk_rows (RowBlocks)
     uint32_t tiles_per_row, n_tiles;
-    // Guards evaluated per rectangle of guard_rows rows x 256 pixels (guard_w32 != 0): bit g of a rectangle's words =
+    // Guards evaluated per rectangle of guard_rows rows x 256 / guard_sub pixels (guard_w32 != 0): bit g of a rectangle's words =
     // guard guard_first + g.  PIXEL reads them instead of y values; the GUARDS kernel (job j = 8 guards = one byte,
     // tape[job_off[j] .. + job_len[j])) writes them.
     uint32_t *gbits;
@@ -60,6 +60,7 @@ struct KArgs {
     uint32_t x_slot;           // run_xtape: slots x_slot, x_slot + 1, x_slot + 2 hold X, Y and the results nothing reads
     const uint32_t *job_off, *job_len;
     uint32_t guard_first, guard_w32, guard_rows;
+    uint32_t guard_sub;            // guard rectangles per 256-pixel tile (1, 2 or 4: a rectangle is 256 / guard_sub pixels wide)
 };
 
 typedef const __attribute__((address_space(4))) uint64_t *k_u64_ptr;   // constant address space: scalar loads
@@ -414,7 +415,9 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_pixels(const KArgs A)
         uint32_t unused = 0;
         Item I{};
         I.yrow = A.yvals + (size_t)r * A.n_yvals;
-        I.gk = A.guard_w32 ? A.gbits + ((size_t)(r / A.guard_rows) * A.tiles_per_row + (tile - r * A.tiles_per_row)) * A.guard_w32 : nullptr;
+        // the guard words of this wavefront's rectangle (a wavefront's 64 pixels lie in one: rectangles are 64 .. 256 wide)
+        I.gk = A.guard_w32 ? A.gbits + (((size_t)(r / A.guard_rows) * A.tiles_per_row + (tile - r * A.tiles_per_row)) * A.guard_sub +
+                                        (threadIdx.x * A.guard_sub) / BLOCK) * A.guard_w32 : nullptr;
         I.X = (double)x; I.Y = (double)y;                                            // p = [x as f64, y as f64]
         if (A.xtape) {
             slots[A.x_slot * BLOCK + threadIdx.x] = I.X;
@@ -469,7 +472,7 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_rows(const KArgs A)
     }
 }
 
-// GUARDS kernel: one work-item per rectangle of guard_rows rows x 256 pixels, blockIdx.y = job (8 guards = one byte
+// GUARDS kernel: one work-item per rectangle of guard_rows rows x 256 / guard_sub pixels, blockIdx.y = job (8 guards = one byte
 // of the rectangle's guard bits; its tape is the cone of those guards: short jobs, many wavefronts -- each is one
 // dependent chain).  XMIN..YMAX = the rectangle's ends.
 __global__ void __launch_bounds__(BLOCK) maray_tape_guards(const KArgs A)
@@ -479,7 +482,8 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_guards(const KArgs A)
     const uint32_t spill_stride = gridDim.x * BLOCK;
     double *spill_base = A.spill ? A.spill + (size_t)blockIdx.x * BLOCK + threadIdx.x : nullptr;
     const uint32_t n_groups = (A.rows + A.guard_rows - 1) / A.guard_rows;
-    const uint32_t n_items = n_groups * A.tiles_per_row;
+    const uint32_t per_row = A.tiles_per_row * A.guard_sub, gw = BLOCK / A.guard_sub;       // rectangles per row of them; their width
+    const uint32_t n_items = n_groups * per_row;
     const uint32_t item_blocks = (n_items + BLOCK - 1) / BLOCK;
     // resident blocks draw (job, block of items) units from a queue, longest jobs first: the grid, and with it the spill
     // area, stays bounded for any image, and a block that drew a short job comes back for more while a long one runs.
@@ -494,9 +498,10 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_guards(const KArgs A)
         const uint32_t job = u / item_blocks;
         const uint32_t it = (u - job * item_blocks) * BLOCK + threadIdx.x;
         const uint32_t item = it < n_items ? it : n_items - 1;         // keep the wave uniform
-        const uint32_t grp = item / A.tiles_per_row, tx = item - grp * A.tiles_per_row;
+        const uint32_t grp = item / per_row, tx = item - grp * per_row;
         const uint32_t r = grp * A.guard_rows, r_last = r + A.guard_rows - 1 < A.rows - 1 ? r + A.guard_rows - 1 : A.rows - 1;
-        const uint32_t xlo = tx * BLOCK, xhi = xlo + BLOCK - 1 < A.w - 1 ? xlo + BLOCK - 1 : A.w - 1;
+        // (the last tile of a ragged row may own rectangles past the edge: they bound the last pixel)
+        const uint32_t xlo_ = tx * gw, xlo = xlo_ < A.w - 1 ? xlo_ : A.w - 1, xhi = xlo_ + gw - 1 < A.w - 1 ? xlo_ + gw - 1 : A.w - 1;
         double o0, o1, o2;
         uint32_t bits = 0;
         Item I{};
@@ -794,12 +799,22 @@ struct TapeBackend final : Backend {
         // guard bits per rectangle: only with this back-end's own ROW pass (a caller's y-value table carries the guards
         // as y values bounded over the row), and only if a group of rows never straddles two row blocks
         const bool bits = tile_guards && !ext_yvals;
-        const uint32_t guard_rows = (bits && (rb.block_rows >= rows || rb.block_rows % 8 == 0)) ? 8u : 1u;
+        // The rectangle a guard is bounded over: 64 pixels x 32 rows, like the specialised path's (jit_backend.cpp,
+        // jit_guard_geom: as many rectangles as 256 x 8, closer to a shape's outline for a wavefront of 64 pixels);
+        // fewer rows when a group would straddle two row blocks.  MARAY_TAPE_GUARD_W / _H: measurement knobs.
+        uint32_t want_rows = 32, guard_sub = 4;
+        if (const char *e_ = getenv("MARAY_TAPE_GUARD_H")) { const int v = atoi(e_); if (v == 8 || v == 16 || v == 32 || v == 64) want_rows = (uint32_t)v; }
+        if (const char *e_ = getenv("MARAY_TAPE_GUARD_W")) { const int v = atoi(e_); if (v == 64 || v == 128 || v == 256) guard_sub = 256u / (uint32_t)v; }
+        uint32_t guard_rows = 1;
+        if (bits)
+            for (uint32_t g = want_rows; g >= 8; g /= 2)
+                if (rb.block_rows >= rows || rb.block_rows % g == 0) { guard_rows = g; break; }
+        if (!bits) guard_sub = 1;
         const uint32_t tiles_per_row = (w + BLOCK - 1) / BLOCK;
         const uint32_t n_groups = (rows + guard_rows - 1) / guard_rows;
         if (bits) {
             const size_t had = gbits_cap;
-            ensure(d_gbits, gbits_cap, (size_t)n_groups * tiles_per_row * n_guard_w32);
+            ensure(d_gbits, gbits_cap, (size_t)n_groups * tiles_per_row * guard_sub * n_guard_w32);
             if (gbits_cap != had) HIP_TRY(hipMemsetAsync(d_gbits, 0, gbits_cap * 4, st));     // bytes past the last job are never written
         }
         if (rows_pass && (n_row_jobs || bits)) {
@@ -824,8 +839,8 @@ struct TapeBackend final : Backend {
                 KArgs G = R;
                 G.tape = d_guard_ops; G.yout = nullptr;
                 G.gbits = d_gbits; G.job_off = d_job_off; G.job_len = d_job_len;
-                G.guard_first = n_ynum; G.guard_w32 = n_guard_w32; G.guard_rows = guard_rows; G.tiles_per_row = tiles_per_row;
-                const uint64_t items = (uint64_t)n_groups * tiles_per_row;
+                G.guard_first = n_ynum; G.guard_w32 = n_guard_w32; G.guard_rows = guard_rows; G.tiles_per_row = tiles_per_row; G.guard_sub = guard_sub;
+                const uint64_t items = (uint64_t)n_groups * tiles_per_row * guard_sub;
                 if (items > 0x7FFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
                 const uint64_t units = ((items + BLOCK - 1) / BLOCK) * n_guard_jobs;        // (job, block of items) pairs
                 const uint32_t resident = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, 163840 / std::max<uint32_t>(guard_lds_bytes, 1)));
@@ -851,7 +866,7 @@ struct TapeBackend final : Backend {
         A.n_slots = P.n_pix_slots; A.n_lds_slots = n_lds_slots;
         A.w = w; A.y0 = y0; A.rows = rows; A.blk_rows = rb.block_rows; A.blk_stride = rb.block_stride;
         A.tiles_per_row = tiles_per_row;
-        if (bits) { A.gbits = d_gbits; A.guard_first = n_ynum; A.guard_w32 = n_guard_w32; A.guard_rows = guard_rows; }
+        if (bits) { A.gbits = d_gbits; A.guard_first = n_ynum; A.guard_w32 = n_guard_w32; A.guard_rows = guard_rows; A.guard_sub = guard_sub; }
         A.xtape = bits ? d_xtape_bits : d_xtape_rows;
         A.queue = d_queue + 1;
         A.x_slot = x_slot;

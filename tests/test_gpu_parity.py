@@ -526,12 +526,13 @@ def test_specialised_kernel_variants_selected_by_tuning_knobs(chess_bytes, monke
 
 def test_interpreter_variants_selected_by_tuning_knobs(chess_bytes, monkeypatch):
     """The interpreter's other paths: the generic loop (what a program whose slots do not fit LDS gets, spill area
-    included), guards evaluated per row as y values (what a scene whose guards read Y gets), and cones kept in the
-    order the ROW section was scheduled in (more live slots: LDS + spill)."""
+    included), guards evaluated per row as y values (what a scene whose guards read Y gets), cones kept in the
+    order the ROW section was scheduled in (more live slots: LDS + spill), other guard rectangles than 64 x 32."""
     g = json.load(open(os.path.join(GOLDEN, 'chess_1024.json')))
     tape = M.Scene(chess_bytes).lower()
     for env in ({'MARAY_TAPE_GENERIC': '1'}, {'MARAY_TAPE_ROW_GUARDS': '1'}, {'MARAY_TAPE_KEEP_ORDER': '1'},
-                {'MARAY_TAPE_GENERIC': '1', 'MARAY_TAPE_KEEP_ORDER': '1'}, {'MARAY_TAPE_ROW_GUARDS': '1', 'MARAY_TAPE_GENERIC': '1'}):
+                {'MARAY_TAPE_GENERIC': '1', 'MARAY_TAPE_KEEP_ORDER': '1'}, {'MARAY_TAPE_ROW_GUARDS': '1', 'MARAY_TAPE_GENERIC': '1'},
+                {'MARAY_TAPE_GUARD_W': '256', 'MARAY_TAPE_GUARD_H': '8'}, {'MARAY_TAPE_GUARD_W': '128', 'MARAY_TAPE_GUARD_H': '64'}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         for b in (M.BACKEND_TAPE_SMEM, M.BACKEND_TAPE):
