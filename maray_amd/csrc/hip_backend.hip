@@ -594,7 +594,7 @@ struct TapeBackend final : Backend {
     double *d_spill = nullptr; size_t spill_cap = 0;
     // Guards per rectangle of pixels (include/maray_tape.h, SPEC XMIN..YMIN): when no guard reads Y, the ROW tape is
     // cut into the cone of the operand y values (run per row) and the cones of the guards, 32 to a job (run per
-    // rectangle of 8 rows x 256 pixels by maray_tape_guards); the pixel kernel then reads guard bits.
+    // rectangle of 32 rows x 64 pixels by maray_tape_guards); the pixel kernel then reads guard bits.
     bool tile_guards = false;
     uint32_t n_ynum = 0, n_guard_jobs = 0, n_guard_w32 = 0;
     uint32_t rows_slots = 0, guard_slots = 0;          // value slots of the cut tapes (renumbered by liveness)
