@@ -416,8 +416,9 @@ __global__ void __launch_bounds__(BLOCK) maray_tape_pixels(const KArgs A)
         Item I{};
         I.yrow = A.yvals + (size_t)r * A.n_yvals;
         // the guard words of this wavefront's rectangle (a wavefront's 64 pixels lie in one: rectangles are 64 .. 256 wide)
+        // (readfirstlane: the index is the same on every lane of a wavefront, and the words must come by scalar loads)
         I.gk = A.guard_w32 ? A.gbits + (((size_t)(r / A.guard_rows) * A.tiles_per_row + (tile - r * A.tiles_per_row)) * A.guard_sub +
-                                        (threadIdx.x * A.guard_sub) / BLOCK) * A.guard_w32 : nullptr;
+                                        (uint32_t)__builtin_amdgcn_readfirstlane((int)((threadIdx.x * A.guard_sub) / BLOCK))) * A.guard_w32 : nullptr;
         I.X = (double)x; I.Y = (double)y;                                            // p = [x as f64, y as f64]
         if (A.xtape) {
             slots[A.x_slot * BLOCK + threadIdx.x] = I.X;
