@@ -1967,7 +1967,11 @@ struct JitBackend final : Backend {
             // (every tile of a program without guards costs the same: long strips, nothing to balance -- config 2 at 8192^2:
             // 2.74 -> 2.88 TB/s with 8 tiles; only for the cheap four-wide sections, a narrow wavefront would live too long)
             const bool coop = k_coop;
-            tiles = coop || wide_all ? 8 : 2;
+            // (a launch that fills the device only a few times over -- chess up to 2048^2 -- is a matter of how long its longest
+            // wavefront lives, not of throughput: one tile per wavefront then; 1024^2 / 2048^2 / 4096^2 / 8192^2 with 1 tile:
+            // 20.3 / 18.9 / 48.4 / 149 us per step, with 2: 25.5 / 24.8 / 42.3 / 138)
+            const uint64_t device_slots = (uint64_t)n_cu * 4 * 7;
+            tiles = coop || wide_all ? 8 : (n_tiles <= 4 * device_slots ? 1 : 2);
             if (k_tiles) tiles = std::min(64u, k_tiles);
             if (n_gwords && n_gwords <= jit_gw_inline_max()) tiles = std::min(tiles, 64u / (n_gwords * guard_sub));
             tiles = std::max(1u, std::min(tiles, n_tx));
