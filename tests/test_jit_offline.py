@@ -155,3 +155,42 @@ def test_helper_processes_build_what_the_process_itself_builds(monkeypatch, tmp_
         code, n = C.c_void_p(), C.c_size_t()
         assert L.maray_jit_build(C.byref(tape.program), C.byref(code), C.byref(n)) == -9          # MARAY_E_HIP
         assert b'notanoption' in L.maray_last_error()
+
+
+def _sources(tape):
+    L = M.lib()
+    L.maray_jit_source.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.maray_jit_source_rows.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
+    out = []
+    for fn, extra in ((L.maray_jit_source, ()), (L.maray_jit_source_rows, (C.byref(C.c_uint32()),))):
+        src = C.c_void_p()
+        assert fn(C.byref(tape.program), C.byref(src), *extra) == 0, L.maray_last_error()
+        out.append(C.string_at(src).decode())
+        L.maray_free(src)
+    return out
+
+
+def test_guard_rectangles_are_the_back_ends_choice(chess_bytes, monkeypatch):
+    """Guards are bounded over rectangles of 64 pixels x 32 rows by default (jit_guard_geom): the ROW kernel's guard items
+    span 64 pixels, the PIXEL kernel tests a tile's twelve words with one ballot and takes a pass's three by v_readlane.
+    Knobs and layouts that test a tile's bits once keep 256-pixel rectangles; a program with more than 12 guard words
+    holds a tile's words one per lane and still gets narrow rectangles when they fit a wavefront's 64 lanes."""
+    tape = M.Scene(chess_bytes).lower()
+    pix, rows = _sources(tape)
+    assert 'tile * 64u' in rows and 'tile * 256u' not in rows
+    assert 'mr_gnz' in pix and '(t * 4u + (e >> 0u)) * 3u' in pix and 'unsigned swz' in pix
+    for env, width, marker in (({'MARAY_JIT_GUARD_W': '128'}, 128, '(t * 2u + (e >> 1u)) * 3u'), ({'MARAY_JIT_GUARD_W': '256'}, 256, 't * 3u + 0u'),
+                               ({'MARAY_JIT_WIDE': '1'}, 256, 't * 3u + 0u'), ({'MARAY_JIT_GW': 'sload'}, 256, 'mr_gk[0u]'),
+                               ({'MARAY_JIT_GW_MANY': '1'}, 64, 'mr_lane64(mr_gt0, mr_gsub + 0u)')):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pix, rows = _sources(tape)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert 'tile * %du' % width in rows, env
+        assert marker in pix, env
+    # 1,000 triangles: 16 guard words per rectangle, four rectangles per tile = the 64 lanes of a wavefront
+    import fuzz_scenes
+    soup = M.Scene(encode((4096, 4096), fuzz_scenes.polygon_soup(7, 1000, 4096, 4096, mixed=False))).lower()
+    pix, rows = _sources(soup)
+    assert 'tile * 64u' in rows and 'mr_lane < 64u ?' in pix and 'mr_gsub' in pix
