@@ -96,7 +96,7 @@ def test_chess_rows_hoisting_on_off(chess_bytes, hoist):
 
 def test_chess_4096_rescaled(chess_bytes):
     """Config 3, the headline configuration, on the kernel the headline number is quoted on (maray_jit_pixels) and on
-    both interpreters.  The specialised kernel's guards are evaluated per 8-row x 256-pixel rectangle and depend on the
+    both interpreters.  The specialised kernel's guards are evaluated per rectangle of 32 rows x 64 pixels and depend on the
     launch geometry, so 1024^2 coverage does not transfer: here the WHOLE 4096^2 raster of every back-end is compared
     byte for byte with the others', the oracle checks bands holding the knife-edge rows (2048..2051, 2816..2819: the
     rows on which images/chess.png differs from IEEE evaluation), the board's first and last rows
