@@ -21,6 +21,7 @@
 
 #include <sys/stat.h>
 #include <unistd.h>
+#include <sstream>
 #include <spawn.h>
 #include <dlfcn.h>
 #include <sys/wait.h>
@@ -1383,8 +1384,11 @@ void jit_compile(const std::string &src, std::vector<char> &code, std::string &l
     const char *names[] = {"device_math.h", "maray_libm.h", "maray_libm_tables.h"};
     RTC_TRY(hiprtcCreateProgram(&prog, src.c_str(), "maray_jit.hip", 3, headers, names));
     const char *olevel = getenv("MARAY_JIT_OPT");          // measurement knob: "-O1" builds faster
-    const char *opts[] = {"--offload-arch=gfx950", (olevel && olevel[0] == '-') ? olevel : "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17"};
-    hiprtcResult rc = hiprtcCompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+    std::vector<const char *> opts = {"--offload-arch=gfx950", (olevel && olevel[0] == '-') ? olevel : "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17"};
+    std::vector<std::string> extra;                        // MARAY_JIT_EXTRA="-mllvm -some-flag ...": measurement knob
+    if (const char *e_ = getenv("MARAY_JIT_EXTRA")) { std::istringstream in(e_); for (std::string w; in >> w;) extra.push_back(w); }
+    for (const std::string &w : extra) opts.push_back(w.c_str());
+    hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     size_t ln = 0;
     hiprtcGetProgramLogSize(prog, &ln);
     log.assign(ln, '\0');
@@ -1503,7 +1507,7 @@ std::string key_salt()
     int major = 0, minor = 0;
     (void)hiprtcVersion(&major, &minor);          // a process that imported PyTorch first compiles with PyTorch's own hiprtc
     return std::string(maray_version()) + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) +
-           "|" + JIT_OPTIONS + "|" + (getenv("MARAY_JIT_OPT") ? getenv("MARAY_JIT_OPT") : "");
+           "|" + JIT_OPTIONS + "|" + (getenv("MARAY_JIT_OPT") ? getenv("MARAY_JIT_OPT") : "") + (getenv("MARAY_JIT_EXTRA") ? std::string("|") + getenv("MARAY_JIT_EXTRA") : std::string());
 }
 
 std::string program_name(const maray_program &prog)
