@@ -912,8 +912,9 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
          "    const unsigned mr_xl = mr_wide ? 4u * mr_lane : mr_lane, mr_xs = mr_wide ? 1u : 64u;\n"
          "    const unsigned mr_src = (mr_lane * 4u) / 3u, mr_shift = ((mr_lane * 4u) % 3u) * 8u;   // RGB8 packing of one 64-pixel run\n"
          "    const size_t row_px = (size_t)r * w;\n"
-         "    unsigned mr_dealt = 0u;                                                  // tiles of this strip that went to ONE wavefront so far\n"
-         "    for (unsigned t = 0; t < tiles; t++) {\n"
+         "    unsigned mr_dealt = 0u;                                                  // tiles of this strip that went to ONE wavefront so far\n";
+    const size_t head_begin = s.size();              // the head of the loop over the strip's tiles (emitted again by the two-loop form below)
+    s += "    for (unsigned t = 0; t < tiles; t++) {\n"
          "    const unsigned x0 = (tile0 + t) * 256u;\n"
          "    if (x0 >= w) break;\n"
 
@@ -940,6 +941,12 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
                      std::to_string(64 * j) + "u + mr_lane] : 0ull;\n";
     }
     if (defer) s += "    ((volatile unsigned *)mr_slow)[mr_wv] = 0u;\n    bool mr_slow_tile = false;\n";
+    const std::string loop_head = s.substr(head_begin);
+    // Two loops over the strip instead of one (MARAY_JIT_TWO_LOOPS=1): first the tiles with no guard bit set, then -- if the
+    // strip has any -- the others.  What the back end hoists out of the busy variant (constants of its libm bodies) then
+    // lands in front of the second loop, which a wavefront of sky never reaches, instead of in every wavefront's prologue.
+    const char *env_tl = getenv("MARAY_JIT_TWO_LOOPS");
+    const bool two_loops = gw_vgpr && sub > 1 && !coop && !persist && !wide_general && env_tl && env_tl[0] == '1';
     // a tile for one wavefront: the block's four take such tiles in turn
     const std::string deal = coop ? "    const bool mr_mine = (mr_dealt & 3u) == mr_wv;\n    mr_dealt++;\n    if (mr_mine) {\n" : "    {\n";
     if (!E.ignore_row_guards) {         // dry run: which ops yield lane masks
@@ -1062,6 +1069,12 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
         E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
         s += wide_close;
         E.assume_guards_zero = false;
+        if (two_loops) {
+            std::string zero = "((mr_gnz >> (t * " + tw + "u)) & " + std::to_string((1ull << (sub * n_gwords)) - 1ull) + "ull) == 0ull";
+            s += tile_end + "    }\n    }\n    }\n"                                     // ... the wide block, `if (no bit set)`, the first loop
+                 "    if (mr_gnz != 0ull) {\n" + loop_head +
+                 "    if (" + zero + ") continue;\n";
+        } else
         s += tile_end + "    }\n    continue;\n    }\n";
     }
     if (wide_general) {
@@ -1146,7 +1159,7 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
                  "    }\n" + tile_end;
         }
     }
-    s += persist ? "    }\n    }\n}\n" : "    }\n}\n";
+    s += persist ? "    }\n    }\n}\n" : two_loops ? "    }\n    }\n}\n" : "    }\n}\n";
     {
         std::string tab = store_run;
         if (!E.ktab_vals.empty()) {
@@ -1156,7 +1169,8 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
         }
         s.replace(s.find("/*MR_KTAB*/"), 11, tab);
         // The table's address, made opaque once per tile and once per pass (see `opaque`)
-        s.replace(s.find("/*MR_KBASE*/"), 12, E.ktab_vals.empty() ? "" : "    unsigned long long mr_kbase = (unsigned long long)mr_kc_tab;\n");
+        for (size_t at; (at = s.find("/*MR_KBASE*/")) != std::string::npos;)
+            s.replace(at, 12, E.ktab_vals.empty() ? "" : "    unsigned long long mr_kbase = (unsigned long long)mr_kc_tab;\n");
         const std::string kc = E.ktab_vals.empty() ? "    asm volatile(\"\" ::: \"memory\");\n" :
                                "    asm volatile(\"\" : \"+s\"(mr_kbase) :: \"memory\");\n"
                                "    const mr_kptr mr_kc = (mr_kptr)mr_kbase;\n";
