@@ -947,6 +947,10 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
     // lands in front of the second loop, which a wavefront of sky never reaches, instead of in every wavefront's prologue.
     const char *env_tl = getenv("MARAY_JIT_TWO_LOOPS");
     const bool two_loops = gw_vgpr && sub > 1 && !coop && !persist && !wide_general && env_tl && env_tl[0] == '1';
+    // =2: a strip with no guard bit at all takes a loop of its own (the wide variant only), any other strip the one loop
+    // with both variants: the busy strips run the code they always ran
+    const bool sky_strips = gw_vgpr && sub > 1 && !coop && !persist && !wide_general && env_tl && env_tl[0] == '2';
+    std::string wide_block;
     // a tile for one wavefront: the block's four take such tiles in turn
     const std::string deal = coop ? "    const bool mr_mine = (mr_dealt & 3u) == mr_wv;\n    mr_dealt++;\n    if (mr_mine) {\n" : "    {\n";
     if (!E.ignore_row_guards) {         // dry run: which ops yield lane masks
@@ -1065,10 +1069,12 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
         }
         E.td = "mr_d"; E.tm = "mr_m";
         E.assume_guards_zero = true;
+        const size_t wide_begin = s.size();
         s += deal + wide_open;
         E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
         s += wide_close;
         E.assume_guards_zero = false;
+        wide_block = s.substr(wide_begin) + tile_end + "    }\n";
         if (two_loops) {
             std::string zero = "((mr_gnz >> (t * " + tw + "u)) & " + std::to_string((1ull << (sub * n_gwords)) - 1ull) + "ull) == 0ull";
             s += tile_end + "    }\n    }\n    }\n"                                     // ... the wide block, `if (no bit set)`, the first loop
@@ -1159,6 +1165,11 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
                  "    }\n" + tile_end;
         }
     }
+    if (sky_strips && !wide_block.empty()) {
+        // (the busy strips' loop first in the code, the sky loop behind it: the placement the busy path had without it)
+        s.insert(head_begin, "    if (mr_gnz != 0ull) {\n");
+        s += "    }\n    } else {                                                                 // a strip of sky\n" + loop_head + wide_block + "    }\n";
+    }          // (the closer below then ends the `else`, not the tile loop)
     s += persist ? "    }\n    }\n}\n" : two_loops ? "    }\n    }\n}\n" : "    }\n}\n";
     {
         std::string tab = store_run;
