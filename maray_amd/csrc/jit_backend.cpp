@@ -1999,8 +1999,11 @@ struct JitBackend final : Backend {
             // (a launch that fills the device only a few times over -- chess up to 2048^2 -- is a matter of how long its longest
             // wavefront lives, not of throughput: one tile per wavefront then; 1024^2 / 2048^2 / 4096^2 / 8192^2 with 1 tile:
             // 20.3 / 18.9 / 48.4 / 149 us per step, with 2: 25.5 / 24.8 / 42.3 / 138)
+            // ... and a launch that fills it dozens of times over is a matter of what every wavefront costs before its first
+            // pixel, its tail is short against the whole: four tiles per wavefront (8192^2 / 16384^2 with 2 / 3 / 4 / 5 tiles:
+            // 138 / 123 / 119 / 139 and 517 / 487 / 497 / 566 us per step; 4096^2: 42.2 / 55.5 / 44.6 / 46.9)
             const uint64_t device_slots = (uint64_t)n_cu * 4 * 7;
-            tiles = coop || wide_all ? 8 : (n_tiles <= 4 * device_slots ? 1 : 2);
+            tiles = coop || wide_all ? 8 : (n_tiles <= 4 * device_slots ? 1 : n_tiles <= 16 * device_slots ? 2 : 4);
             if (k_tiles) tiles = std::min(64u, k_tiles);
             if (n_gwords && n_gwords <= jit_gw_inline_max()) tiles = std::min(tiles, 64u / (n_gwords * guard_sub));
             tiles = std::max(1u, std::min(tiles, n_tx));
