@@ -1804,7 +1804,7 @@ struct JitBackend final : Backend {
     uint32_t n_row_chunks = 1, n_gwords = 0, n_gjobs = 0, guard_rows = 1, guard_sub = 1;       // guard_sub: guard rectangles per 256-pixel tile
     uint32_t n_cu = 256;
     // launch-time tuning knobs, read once when the context is created
-    bool k_overlap = false, k_coop = false, k_persist = false, wide_all = false, k_swz = true;
+    bool k_overlap = false, k_coop = false, k_persist = false, wide_all = false, k_swz = false;
     unsigned k_row_block = 256, k_tiles = 0, k_per_cu = 7;
     uint32_t px = 4;                    // pixels per lane of the PIXEL kernel this context was built with
     bool has_sin = false;               // some Sin argument is not proven bounded: tiles may be deferred to `slow`
@@ -1851,7 +1851,11 @@ struct JitBackend final : Backend {
         k_coop = jit_coop(); k_persist = jit_persist();
         wide_all = jit_wide_general(prog);
         if (const char *e_ = getenv("MARAY_JIT_ROW_OVERLAP")) k_overlap = e_[0] == '1';
-        if (const char *e_ = getenv("MARAY_JIT_SWIZZLE")) k_swz = e_[0] != '0';
+        // MARAY_JIT_SWIZZLE=1: a row's blocks take its strips rotated by the row (the kernel's `swz`), so that a column of the
+        // image meets every XCD.  Measured both ways: chess @16384^2 with 8 blocks per row 530 -> 517 us per frame, with 4
+        // blocks per row (what such a launch takes now) 474 -> 498; 2 blocks per row, symmetric or lopsided scene: nothing.
+        // Off by default.
+        if (const char *e_ = getenv("MARAY_JIT_SWIZZLE")) k_swz = e_[0] == '1';
         k_row_block = jit_row_block();
         if (const char *e_ = getenv("MARAY_JIT_TILES")) if (atoi(e_) > 0) k_tiles = (unsigned)atoi(e_);
         if (const char *e_ = getenv("MARAY_JIT_BLOCKS_PER_CU")) if (atoi(e_) > 0) k_per_cu = (unsigned)atoi(e_);

@@ -509,7 +509,7 @@ def test_specialised_kernel_variants_selected_by_tuning_knobs(chess_bytes, monke
                 {'MARAY_JIT_GW_MANY': '1'}, {'MARAY_JIT_GW_MANY': '1', 'MARAY_JIT_TILES': '5'},
                 {'MARAY_JIT_GUARD_W': '256', 'MARAY_JIT_GUARD_H': '8'}, {'MARAY_JIT_GUARD_W': '128', 'MARAY_JIT_GUARD_H': '16', 'MARAY_JIT_TILES': '3'},
                 {'MARAY_JIT_GUARD_W': '64', 'MARAY_JIT_GUARD_H': '128'}, {'MARAY_JIT_PASS_SKY': '1'}, {'MARAY_JIT_GUARD_W': '256', 'MARAY_JIT_NARROW': '2'},
-                {'MARAY_JIT_TILES': '7'}, {'MARAY_JIT_SWIZZLE': '0'}, {'MARAY_JIT_EXPECT': '0'}, {'MARAY_JIT_TWO_LOOPS': '1'}, {'MARAY_JIT_TWO_LOOPS': '1', 'MARAY_JIT_TILES': '5'}, {'MARAY_JIT_TWO_LOOPS': '2'}, {'MARAY_JIT_TWO_LOOPS': '2', 'MARAY_JIT_TILES': '3'}, {'MARAY_JIT_ROW_MIN_REGION': '0'}, {'MARAY_JIT_ROW_MIN_REGION': '100000'},
+                {'MARAY_JIT_TILES': '7'}, {'MARAY_JIT_SWIZZLE': '1'}, {'MARAY_JIT_SWIZZLE': '1', 'MARAY_JIT_TILES': '1'}, {'MARAY_JIT_EXPECT': '0'}, {'MARAY_JIT_TWO_LOOPS': '1'}, {'MARAY_JIT_TWO_LOOPS': '1', 'MARAY_JIT_TILES': '5'}, {'MARAY_JIT_TWO_LOOPS': '2'}, {'MARAY_JIT_TWO_LOOPS': '2', 'MARAY_JIT_TILES': '3'}, {'MARAY_JIT_ROW_MIN_REGION': '0'}, {'MARAY_JIT_ROW_MIN_REGION': '100000'},
                 {'MARAY_JIT_PAD_GRID': '3'}, {'MARAY_JIT_TILES': '1', 'MARAY_JIT_PAD_GRID': '2'},
                 px1, dict(px1, MARAY_JIT_YLDS='1'), dict(px1, MARAY_JIT_ROW_GUARDS='0'), dict(px1, MARAY_JIT_TILES='1'), dict(px1, MARAY_JIT_KTAB='0'),
                 dict(px1, MARAY_JIT_ROW_BLOCK='64', MARAY_JIT_TILES='3'), dict(px1, MARAY_JIT_GLDS='0'), dict(px1, MARAY_JIT_ROWS_REVERSED='1')):

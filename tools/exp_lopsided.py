@@ -22,7 +22,7 @@ data = encode((4096, 4096), fuzz_scenes.polygon_soup(1, 300, 2048, 4096, mixed=F
 tape = M.Scene(data).lower()
 out = {}
 ref = None
-for name, env in (('rotated (default)', {}), ('in place', {'MARAY_JIT_SWIZZLE': '0'}), ('rotated again', {})):
+for name, env in (('in place (default)', {}), ('rotated', {'MARAY_JIT_SWIZZLE': '1'}), ('in place again', {})):
     os.environ.update(env)
     ctx = M.Context(tape, backend=M.BACKEND_JIT)
     got, _ = ctx.render_rows(4096, 4096, 1000, 1064, want_f64=False)
