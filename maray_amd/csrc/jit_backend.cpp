@@ -20,6 +20,8 @@
 #include <hip/hiprtc.h>
 
 #include <sys/stat.h>
+#include <fcntl.h>
+#include <csignal>
 #include <unistd.h>
 #include <sstream>
 #include <spawn.h>
@@ -1527,11 +1529,17 @@ std::string hex128(uint64_t h1, uint64_t h2)
     return buf;
 }
 
+std::string hiprtc_path();
+
 std::string key_salt()
 {
     int major = 0, minor = 0;
     (void)hiprtcVersion(&major, &minor);          // a process that imported PyTorch first compiles with PyTorch's own hiprtc
-    return std::string(maray_version()) + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) +
+    // ... and two builds of one version are two compilers: the library's path, size and modification time name the binary
+    std::string rtc_id = hiprtc_path();
+    struct stat st;
+    if (!rtc_id.empty() && stat(rtc_id.c_str(), &st) == 0) rtc_id += ":" + std::to_string((long long)st.st_size) + ":" + std::to_string((long long)st.st_mtime);
+    return std::string(maray_version()) + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) + " " + rtc_id +
            "|" + JIT_OPTIONS + "|" + (getenv("MARAY_JIT_OPT") ? getenv("MARAY_JIT_OPT") : "") + (getenv("MARAY_JIT_EXTRA") ? std::string("|") + getenv("MARAY_JIT_EXTRA") : std::string());
 }
 
@@ -1608,8 +1616,9 @@ CodeKey code_key(const maray_program &prog)
 // hiprtc serialises compiles inside a process (two threads: 7.9 s either way for chess, measured), and an LLVM abort
 // inside it takes the process down.  So a program's two modules are built by two helper processes side by side
 // (maray_jitc, next to this library; it dlopens the very hiprtc this process has loaded -- the compiler's version is
-// part of the code key): chess cold 2.6 -> 1.6 s.  MARAY_JIT_HELPER=0, a missing helper or one that dies: the module is
-// compiled in-process as before.  A source that does not compile is an error either way, with the compiler's log.
+// part of the code key): chess cold 2.6 -> 1.6 s.  MARAY_JIT_HELPER=0, or a helper that is missing or cannot reach the
+// compiler: the module is compiled in-process.  A source that does not compile is an error either way, with the
+// compiler's log; a helper that dies while compiling is an error too (MARAY_E_HIP; BACKEND_AUTO then takes the interpreter).
 std::string self_dir()
 {
     Dl_info info;
@@ -1628,7 +1637,7 @@ std::string hiprtc_path()
 
 struct HelperJob {
     pid_t pid = -1;
-    std::string src_path, out_path;
+    std::string dir, src_path, out_path;
 };
 
 bool read_file(const std::string &path, std::vector<char> &out)
@@ -1642,19 +1651,22 @@ bool read_file(const std::string &path, std::vector<char> &out)
     return true;
 }
 
-// starts the helper on `src`; pid stays -1 when it cannot be started
+// starts the helper on `src`; pid stays -1 when it cannot be started.  Source and result live in a directory of their own
+// (mkdtemp, 0700): nobody else can put a file or a link where the helper writes and this process reads.
 HelperJob helper_start(const std::string &helper, const std::string &rtc, const std::string &src, const char *tag)
 {
     HelperJob j;
     const char *tmp = getenv("TMPDIR");
     char path[512];
     snprintf(path, sizeof path, "%s/maray_jit_%ld_%s_XXXXXX", (tmp && tmp[0]) ? tmp : "/tmp", (long)getpid(), tag);
-    const int fd = mkstemp(path);
+    if (!mkdtemp(path)) return j;
+    j.dir = path;
+    j.src_path = j.dir + "/kernel.hip";
+    j.out_path = j.dir + "/kernel.out";
+    const int fd = open(j.src_path.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
     if (fd < 0) return j;
     const bool ok = write(fd, src.data(), src.size()) == (ssize_t)src.size();
     close(fd);
-    j.src_path = path;
-    j.out_path = j.src_path + ".out";
     if (!ok) return j;
     const char *olevel = getenv("MARAY_JIT_OPT");
     std::vector<char *> argv = {(char *)helper.c_str(), (char *)rtc.c_str(), (char *)j.src_path.c_str(), (char *)j.out_path.c_str()};
@@ -1665,24 +1677,42 @@ HelperJob helper_start(const std::string &helper, const std::string &rtc, const 
     return j;
 }
 
-// 0: `code` holds the code object; 3: `log` holds the compiler's errors; else: the helper failed
-int helper_finish(HelperJob &j, std::vector<char> &code, std::string &log)
+// What became of a helper.  OK: `code` holds the code object.  REJECTED: the source does not compile, `log` holds the
+// compiler's errors.  ABSENT: the helper never got as far as the compiler (not started, could not load hiprtc or read its
+// input): the caller compiles in-process.  DIED: the helper was running the compiler and ended by a signal or an
+// unexpected status -- an abort inside LLVM is what the helper exists to keep out of the caller, so this is an error,
+// never a reason to run the same compile in-process; `log` says how it ended and where its source was kept.
+enum HelperEnd { HELPER_OK, HELPER_REJECTED, HELPER_ABSENT, HELPER_DIED };
+
+HelperEnd helper_finish(HelperJob &j, std::vector<char> &code, std::string &log)
 {
-    int rc = -1;
+    HelperEnd end = HELPER_ABSENT;
     if (j.pid > 0) {
         int status = 0;
         pid_t r;
         do r = waitpid(j.pid, &status, 0); while (r < 0 && errno == EINTR);
-        if (r == j.pid && WIFEXITED(status)) rc = WEXITSTATUS(status);
         std::vector<char> out;
-        if ((rc == 0 || rc == 3) && read_file(j.out_path, out)) {
-            if (rc == 0) code.swap(out); else log.assign(out.begin(), out.end());
-        } else if (rc == 0 || rc == 3) rc = -1;
-        if (rc == 0 && (code.size() < 64 || memcmp(code.data(), "\177ELF", 4) != 0)) rc = -1;
+        if (r != j.pid) { end = HELPER_DIED; log = "waitpid failed"; }
+        else if (WIFSIGNALED(status)) { end = HELPER_DIED; log = "signal " + std::to_string(WTERMSIG(status)) + (WTERMSIG(status) == SIGABRT ? " (abort)" : ""); }
+        else if (!WIFEXITED(status)) { end = HELPER_DIED; log = "wait status " + std::to_string(status); }
+        else switch (WEXITSTATUS(status)) {
+        case 0:
+            if (read_file(j.out_path, out) && out.size() >= 64 && memcmp(out.data(), "\177ELF", 4) == 0) { code.swap(out); end = HELPER_OK; }
+            else { end = HELPER_DIED; log = "exit status 0 without a code object"; }
+            break;
+        case 3:
+            if (read_file(j.out_path, out)) { log.assign(out.begin(), out.end()); end = HELPER_REJECTED; }
+            else { end = HELPER_DIED; log = "exit status 3 without a compiler log"; }
+            break;
+        case 2: case 4: case 5: case 127: end = HELPER_ABSENT; break;      // usage / no hiprtc / no input / not executable: the compiler never ran
+        default: end = HELPER_DIED; log = "exit status " + std::to_string(WEXITSTATUS(status));
+        }
     }
-    if (!j.src_path.empty()) (void)unlink(j.src_path.c_str());
+    if (end == HELPER_DIED && !j.src_path.empty()) log += "; source kept in " + j.src_path;      // for the bug report
+    else if (!j.src_path.empty()) (void)unlink(j.src_path.c_str());
     if (!j.out_path.empty()) (void)unlink(j.out_path.c_str());
-    return rc;
+    if (!j.dir.empty() && end != HELPER_DIED) (void)rmdir(j.dir.c_str());
+    return end;
 }
 
 std::shared_ptr<const JitCode> build_code(const maray_program &prog, CodeKey &k)
@@ -1701,10 +1731,12 @@ std::shared_ptr<const JitCode> build_code(const maray_program &prog, CodeKey &k)
             HelperJob jp = helper_start(helper, rtc, k.src_pix, "pix"), jr;
             if (prog.n_row_ops) jr = helper_start(helper, rtc, k.src_rows, "rows");
             std::string lp, lr;
-            const int rp = helper_finish(jp, c->pix, lp), rr = prog.n_row_ops ? helper_finish(jr, c->rows, lr) : -1;
-            if (rp == 3) throw Error{MARAY_E_HIP, "hiprtcCompileProgram (maray_jitc): the PIXEL kernel does not compile\n" + lp};
-            if (rr == 3) throw Error{MARAY_E_HIP, "hiprtcCompileProgram (maray_jitc): the ROW kernel does not compile\n" + lr};
-            have_pix = rp == 0; have_rows = rr == 0;
+            const HelperEnd rp = helper_finish(jp, c->pix, lp), rr = prog.n_row_ops ? helper_finish(jr, c->rows, lr) : HELPER_ABSENT;
+            if (rp == HELPER_REJECTED) throw Error{MARAY_E_HIP, "hiprtcCompileProgram (maray_jitc): the PIXEL kernel does not compile\n" + lp};
+            if (rr == HELPER_REJECTED) throw Error{MARAY_E_HIP, "hiprtcCompileProgram (maray_jitc): the ROW kernel does not compile\n" + lr};
+            if (rp == HELPER_DIED) throw Error{MARAY_E_HIP, "the compiler aborted on the PIXEL kernel (maray_jitc: " + lp + ")"};
+            if (rr == HELPER_DIED) throw Error{MARAY_E_HIP, "the compiler aborted on the ROW kernel (maray_jitc: " + lr + ")"};
+            have_pix = rp == HELPER_OK; have_rows = rr == HELPER_OK;
         }
     }
     // Occupancy: the highest of 8 / 6 / 4 waves per SIMD (<= 64 / 80 / 128 VGPRs) whose build needs no scratch:

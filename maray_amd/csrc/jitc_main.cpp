@@ -2,8 +2,9 @@
 // library the caller names (the one the calling process has loaded: its version is part of the code key), in a process of
 // its own: libmaray_hip.so starts one per module so that the PIXEL and the ROW kernels of a program build side by side
 // (hiprtc serialises compiles inside a process), and an LLVM abort ends this process, not the caller's.
-// Exit status 0: OUT holds the code object; 3: the source does not compile, OUT holds the log; anything else: the
-// helper itself failed (the caller then compiles in-process).
+// Exit status 0: OUT holds the code object; 3: the source does not compile, OUT holds the log; 2, 4, 5: the helper never
+// reached the compiler (usage, no hiprtc, no input: the caller then compiles in-process); a signal or anything else: it
+// died compiling -- the caller reports MARAY_E_HIP and does NOT repeat the compile in its own process.
 #include <dlfcn.h>
 
 #include <cstdio>
@@ -57,6 +58,8 @@ int main(int argc, char **argv)
     }
     const char *headers[] = {maray_embedded_device_math_h, maray_embedded_libm_h, maray_embedded_libm_tables_h};
     const char *names[] = {"device_math.h", "maray_libm.h", "maray_libm_tables.h"};
+    // MARAY_JITC_TEST_ABORT=1 (tests): end the way an LLVM abort inside hiprtc ends this process, once the compiler is at hand
+    if (const char *e_ = getenv("MARAY_JITC_TEST_ABORT")) if (e_[0] == '1') abort();
     hiprtcProgram prog;
     if (create(&prog, src.c_str(), "maray_jit.hip", 3, headers, names) != 0) return 6;
     const char *olevel = argc > 4 && argv[4][0] == '-' ? argv[4] : "-O3";

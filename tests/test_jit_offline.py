@@ -1,4 +1,5 @@
 """The hiprtc back-end generates and compiles gfx950 code without a GPU."""
+import os
 import ctypes as C
 
 import maray_amd as M
@@ -155,6 +156,33 @@ def test_helper_processes_build_what_the_process_itself_builds(monkeypatch, tmp_
         code, n = C.c_void_p(), C.c_size_t()
         assert L.maray_jit_build(C.byref(tape.program), C.byref(code), C.byref(n)) == -9          # MARAY_E_HIP
         assert b'notanoption' in L.maray_last_error()
+
+
+def test_a_helper_that_dies_compiling_is_an_error_not_a_retry_in_process(monkeypatch, tmp_path):
+    """An LLVM abort inside hiprtc is what the helper keeps out of the caller (gpu_tests5.log of round 2: `Fatal Python
+    error: Aborted` inside M.Context).  MARAY_JITC_TEST_ABORT=1 makes the helper end that way: the build comes back as
+    MARAY_E_HIP naming the signal and the kept source, this process lives on, nothing lands in the cache -- and the same
+    source is NOT compiled in-process (it would have built fine there, so success would mean exactly that retry)."""
+    import glob
+    monkeypatch.setenv('AMD_COMGR_CACHE', '0')
+    monkeypatch.setenv('MARAY_JIT_HELPER', '1')
+    monkeypatch.setenv('MARAY_JITC_TEST_ABORT', '1')
+    monkeypatch.setenv('MARAY_CACHE_DIR', str(tmp_path / 'cache'))
+    monkeypatch.setenv('TMPDIR', str(tmp_path))
+    tape = M.Scene(encode((80, 48), scenes.all_ops(80, 48))).lower()      # a program no other test of this process has built
+    L = M.lib()
+    code, n = C.c_void_p(), C.c_size_t()
+    assert L.maray_jit_build(C.byref(tape.program), C.byref(code), C.byref(n)) == -9          # MARAY_E_HIP
+    msg = L.maray_last_error().decode()
+    assert 'compiler aborted' in msg and 'signal 6' in msg and 'source kept in' in msg, msg
+    kept = glob.glob(str(tmp_path / 'maray_jit_*_pix_*' / 'kernel.hip'))
+    assert kept and 'maray_jit_pixels' in open(kept[0]).read()
+    assert (os.stat(os.path.dirname(kept[0])).st_mode & 0o777) == 0o700                        # a directory of its own
+    assert not tape.jit_code_cached
+    # the process survived and the library still works: without the knob the same program builds
+    monkeypatch.delenv('MARAY_JITC_TEST_ABORT')
+    _, blob = build(tape)
+    assert blob[:4] == b'\x7fELF'
 
 
 def _sources(tape):
