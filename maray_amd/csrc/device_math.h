@@ -25,12 +25,6 @@ MARAY_DEV double mr_mask_f64(mr_mask m, unsigned on, unsigned off)
     asm("s_mov_b64 vcc, %3\n\tv_cndmask_b32_e32 %0, %1, %2, vcc" : "=v"(hi) : "v"(off), "v"(on), "s"(m) : "vcc");
     return __builtin_bit_cast(double, (unsigned long long)hi << 32);
 }
-// a value every lane holds alike (read from LDS) -> SGPR pair
-MARAY_DEV mr_mask mr_uniform64(mr_mask v)
-{
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return ((mr_mask)hi << 32) | lo;
-}
 MARAY_DEV double mr_pos(mr_mask m) { return mr_mask_f64(m, 0x3ff00000u, 0u); }               /* +1.0 : +0.0 */
 MARAY_DEV double mr_neg01(mr_mask m) { return mr_mask_f64(m, 0xbff00000u, 0x80000000u); }    /* -1.0 : -0.0 */
 
@@ -187,43 +181,4 @@ MARAY_DEV mr_d mr_app(const MarayTex *tex, unsigned id, const mr_d &x, const mr_
     return mr_d(mr_app(tex, id, x.a, y.a), mr_app(tex, id, x.b, y.b), mr_app(tex, id, x.c, y.c), mr_app(tex, id, x.d, y.d));
 }
 
-// ---- two pixels per lane (MARAY_JIT_NARROW=2: the busy-tile variant in two passes of 128 pixels) ------------------
-struct mr_d2 {
-    double a, b;
-    MARAY_DEV mr_d2() {}
-    MARAY_DEV mr_d2(double s) : a(s), b(s) {}
-    MARAY_DEV mr_d2(double a_, double b_) : a(a_), b(b_) {}
-};
-struct mr_m2 {
-    mr_mask a, b;
-    MARAY_DEV mr_m2() {}
-    MARAY_DEV mr_m2(mr_mask s) : a(s), b(s) {}
-    MARAY_DEV mr_m2(mr_mask a_, mr_mask b_) : a(a_), b(b_) {}
-};
-#define MR_EACH2(f, v) mr_d2(f((v).a), f((v).b))
-MARAY_DEV mr_d2 operator+(const mr_d2 &x, const mr_d2 &y) { return mr_d2(x.a + y.a, x.b + y.b); }
-MARAY_DEV mr_d2 operator*(const mr_d2 &x, const mr_d2 &y) { return mr_d2(x.a * y.a, x.b * y.b); }
-MARAY_DEV mr_m2 operator&(const mr_m2 &x, const mr_m2 &y) { return mr_m2(x.a & y.a, x.b & y.b); }
-MARAY_DEV mr_m2 operator|(const mr_m2 &x, const mr_m2 &y) { return mr_m2(x.a | y.a, x.b | y.b); }
-MARAY_DEV mr_m2 operator~(const mr_m2 &x) { return mr_m2(~x.a, ~x.b); }
-MARAY_DEV bool mr_any(const mr_m2 &m) { return (m.a | m.b) != MR_NONE; }
-MARAY_DEV mr_d2 mr_pos(const mr_m2 &m) { return mr_d2(mr_pos(m.a), mr_pos(m.b)); }
-MARAY_DEV mr_d2 mr_neg01(const mr_m2 &m) { return mr_d2(mr_neg01(m.a), mr_neg01(m.b)); }
-MARAY_DEV mr_m2 mr_ge0(const mr_d2 &v) { return mr_m2(mr_ge0(v.a), mr_ge0(v.b)); }
-MARAY_DEV mr_m2 mr_ne0(const mr_d2 &v) { return mr_m2(mr_ne0(v.a), mr_ne0(v.b)); }
-MARAY_DEV mr_m2 mr_ne1(const mr_d2 &v) { return mr_m2(mr_ne1(v.a), mr_ne1(v.b)); }
-MARAY_DEV mr_m2 mr_stepsin_bounded_m(const mr_d2 &v) { return mr_m2(mr_stepsin_bounded_m(v.a), mr_stepsin_bounded_m(v.b)); }
-MARAY_DEV mr_d2 mr_neg(const mr_d2 &v) { return MR_EACH2(mr_neg, v); }
-MARAY_DEV mr_d2 mr_abs(const mr_d2 &v) { return MR_EACH2(mr_abs, v); }
-MARAY_DEV mr_d2 mr_recip(const mr_d2 &v) { return MR_EACH2(mr_recip, v); }
-MARAY_DEV mr_d2 mr_sqrt(const mr_d2 &v) { return MR_EACH2(mr_sqrt, v); }
-MARAY_DEV mr_d2 mr_sin(const mr_d2 &v) { return MR_EACH2(mr_sin, v); }
-MARAY_DEV mr_d2 mr_sin_bounded(const mr_d2 &v) { return MR_EACH2(mr_sin_bounded, v); }
-MARAY_DEV mr_d2 mr_exp(const mr_d2 &v) { return MR_EACH2(mr_exp, v); }
-MARAY_DEV mr_d2 mr_ln(const mr_d2 &v) { return MR_EACH2(mr_ln, v); }
-MARAY_DEV mr_d2 mr_stepsin(const mr_d2 &v) { return MR_EACH2(mr_stepsin, v); }
-MARAY_DEV mr_d2 mr_stepsin_fast(const mr_d2 &v, float *defer) { return mr_d2(mr_stepsin_fast(v.a, defer), mr_stepsin_fast(v.b, defer)); }
-MARAY_DEV mr_d2 mr_max(const mr_d2 &x, const mr_d2 &y) { return mr_d2(mr_max(x.a, y.a), mr_max(x.b, y.b)); }
-MARAY_DEV mr_d2 mr_min(const mr_d2 &x, const mr_d2 &y) { return mr_d2(mr_min(x.a, y.a), mr_min(x.b, y.b)); }
-MARAY_DEV mr_d2 mr_app(const MarayTex *tex, unsigned id, const mr_d2 &x, const mr_d2 &y) { return mr_d2(mr_app(tex, id, x.a, y.a), mr_app(tex, id, x.b, y.b)); }
 #endif

@@ -618,6 +618,7 @@ struct TapeBackend final : Backend {
     hipEvent_t handover = nullptr;
     // launch geometry of the pixel kernel
     uint32_t n_lds_slots = 0, lds_bytes = 0, blocks_per_cu = 1;
+    uint32_t k_guard_h = 32, k_guard_sub = 4;           // MARAY_TAPE_GUARD_H / _W, read once in init()
     uint32_t row_lds_slots = 0, row_lds_bytes = 0;
     std::string kname;
 
@@ -651,6 +652,8 @@ struct TapeBackend final : Backend {
         n_ynum = numeric_yvals(prog);
         const uint32_t n_guards = prog.n_yvals - n_ynum;
         tile_guards = n_guards > 0 && prog.n_row_ops > 0 && !any_guard_reads_y(prog) && !getenv("MARAY_TAPE_ROW_GUARDS");
+        if (const char *e_ = getenv("MARAY_TAPE_GUARD_H")) { const int v = atoi(e_); if (v == 8 || v == 16 || v == 32 || v == 64) k_guard_h = (uint32_t)v; }
+        if (const char *e_ = getenv("MARAY_TAPE_GUARD_W")) { const int v = atoi(e_); if (v == 64 || v == 128 || v == 256) k_guard_sub = 256u / (uint32_t)v; }
         std::vector<uint64_t> rows_host, guards_host;
         const bool keep_order = getenv("MARAY_TAPE_KEEP_ORDER") != nullptr;
         const RowTapeDeps deps = row_tape_deps(prog);
@@ -802,10 +805,8 @@ struct TapeBackend final : Backend {
         const bool bits = tile_guards && !ext_yvals;
         // The rectangle a guard is bounded over: 64 pixels x 32 rows, like the specialised path's (jit_backend.cpp,
         // jit_guard_geom: as many rectangles as 256 x 8, closer to a shape's outline for a wavefront of 64 pixels);
-        // fewer rows when a group would straddle two row blocks.  MARAY_TAPE_GUARD_W / _H: measurement knobs.
-        uint32_t want_rows = 32, guard_sub = 4;
-        if (const char *e_ = getenv("MARAY_TAPE_GUARD_H")) { const int v = atoi(e_); if (v == 8 || v == 16 || v == 32 || v == 64) want_rows = (uint32_t)v; }
-        if (const char *e_ = getenv("MARAY_TAPE_GUARD_W")) { const int v = atoi(e_); if (v == 64 || v == 128 || v == 256) guard_sub = 256u / (uint32_t)v; }
+        // fewer rows when a group would straddle two row blocks.  MARAY_TAPE_GUARD_W / _H (read at context creation): measurement knobs.
+        uint32_t want_rows = k_guard_h, guard_sub = k_guard_sub;
         uint32_t guard_rows = 1;
         if (bits)
             for (uint32_t g = want_rows; g >= 8; g /= 2)
@@ -874,8 +875,7 @@ struct TapeBackend final : Backend {
         const uint64_t tiles = (uint64_t)A.tiles_per_row * rows;
         if (tiles > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
         A.n_tiles = (uint32_t)tiles;
-        uint32_t per_cu = blocks_per_cu;
-        if (const char *e_ = getenv("MARAY_TAPE_BLOCKS_PER_CU")) if (atoi(e_) > 0) per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(e_));   // diagnosis: occupancy
+        const uint32_t per_cu = blocks_per_cu;
         const uint32_t grid = (uint32_t)std::min<uint64_t>(tiles, (uint64_t)prop.multiProcessorCount * per_cu);
         if (P.n_pix_slots > n_lds_slots) {
             ensure(d_spill, spill_cap, std::max(spill_cap, (size_t)(P.n_pix_slots - n_lds_slots) * grid * BLOCK));

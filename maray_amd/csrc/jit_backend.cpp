@@ -151,8 +151,7 @@ struct Emitter {
     std::vector<uint8_t> ybool;                 // PIXEL in: per y value; ROW out (dry run): what each OUT wrote
     std::vector<uint8_t> out_is_bool;
     const GuardPlan *plan = nullptr;            // guard -> bit(s) (identity when null)
-    uint32_t gw_inline_max = 12;
-    bool gw_lanes = false;                      // > 12 guard words: lane i of mr_gt<j> holds word 64 j + i of the tile at hand
+    uint32_t gw_inline_max = 12;                // > 12 guard words: lane i of mr_gt<j> holds word 64 j + i of the tile at hand
     std::string gw_lane_base;                   // narrow rectangles: lane (this expression) + i of mr_gt0 holds word i of the pass's rectangle
     int stage_first = -1;                       // ROW: >= 0: OUT k goes to LDS, ys[(k - stage_first) * 68 + lane] (jit_source_rows)
     std::string td = "double", tm = "mr_mask";  // types of a value / a boolean in the generated text ("mr_d" / "mr_m": four pixels per lane)
@@ -265,13 +264,11 @@ struct Emitter {
                 if (row_guard && !nz && guard_words && MARAY_REF_INDEX(gref) >= guard_first) {
                     // a row bound: one bit of a guard word that sits in an SGPR since the kernel's prologue
                     const uint32_t g = MARAY_REF_INDEX(gref) - guard_first;
-                    // a guard word: an SGPR pair by name (<= 12 words); beyond, lane wi % 64 of a per-lane value (one v_readlane
-                    // pair, the wave layout) or a word staged in LDS (the first layout)
+                    // a guard word: an SGPR pair by name (<= 12 words); beyond, lane wi % 64 of a per-lane value (one v_readlane pair)
                     auto word = [&](uint32_t wi) {
                         if (guard_words <= gw_inline_max) return "gq" + std::to_string(wi);
-                        if (gw_lanes && !gw_lane_base.empty()) return "mr_lane64(mr_gt0, " + gw_lane_base + " + " + std::to_string(wi) + "u)";
-                        if (gw_lanes) return "mr_lane64(mr_gt" + std::to_string(wi / 64) + ", " + std::to_string(wi % 64) + "u)";
-                        return "mr_uniform64(mr_gqt[" + std::to_string(wi) + "])";
+                        if (!gw_lane_base.empty()) return "mr_lane64(mr_gt0, " + gw_lane_base + " + " + std::to_string(wi) + "u)";
+                        return "mr_lane64(mr_gt" + std::to_string(wi / 64) + ", " + std::to_string(wi % 64) + "u)";
                     };
                     // tests on 32-bit halves of the words: s_and_b32 sets SCC and the branch follows (a 64-bit test is
                     // s_and + s_cmp_u64 + the branch, on the unit that bounds the busy tiles)
@@ -306,10 +303,8 @@ struct Emitter {
                 // A region behind a rectangle guard is entered rarely (chess: 4 of the 15 a pass tests): unlikely, so that the block
                 // placement keeps the skip path as the fall-through and moves the bodies out of line (taken jumps stall on
                 // instruction fetch).  A wave-level region of the PIXEL section sits inside a shape whose guard let the wavefront
-                // in, and is entered nine times in ten (18 of 20 per pass): likely (board crop 82.3 -> 81.6 us; MARAY_JIT_EXPECT=0:
-                // every region unlikely, as it was).
-                const bool expect_wave = !(getenv("MARAY_JIT_EXPECT") && getenv("MARAY_JIT_EXPECT")[0] == '0');
-                out += "    if (__builtin_expect(" + cond + (expect_wave && pixel && !row_guard ? ", 1)) {\n" : ", 0)) {\n");
+                // in, and is entered nine times in ten (18 of 20 per pass): likely (board crop 82.3 -> 81.6 us).
+                out += "    if (__builtin_expect(" + cond + (pixel && !row_guard ? ", 1)) {\n" : ", 0)) {\n");
                 open.push_back(Open{end, typed_bool, nz, next_scope++});
                 ktab_block.clear();
                 continue;
@@ -438,12 +433,11 @@ struct Emitter {
 }   // namespace
 
 // Which y values are booleans: a dry run of the emitter over the ROW section (its typing is the one the PIXEL section
-// will rely on).  MARAY_JIT_YBOOL=0: none (ablation).
+// will rely on).
 std::vector<uint8_t> jit_bool_yvals(const maray_program &P)
 {
     std::vector<uint8_t> r(P.n_yvals, 0);
-    const char *e_ = getenv("MARAY_JIT_YBOOL");
-    if (!P.n_row_ops || (e_ && e_[0] == '0')) return r;
+    if (!P.n_row_ops) return r;
     Emitter D(P);
     D.section(P.row_ops, P.n_row_ops, P.n_row_slots, false, "r");
     const uint32_t n_ynum = numeric_yvals(P);
@@ -454,15 +448,13 @@ std::vector<uint8_t> jit_bool_yvals(const maray_program &P)
 // The guard plan of a program (GuardPlan).  A guard is derived when its source is a MAX tree, boolean-typed all the way
 // (on {+0.0, 1.0} max is OR, so "value != 0" distributes over it exactly), whose leaves are sources of other guards.
 // Bits are handed out in the order the members are met, so that a group's bits are neighbours (one word, one s_and).
-// MARAY_JIT_DERIVED=0: every guard gets its bit and its job (ablation).
 GuardPlan jit_guard_plan(const maray_program &P)
 {
     GuardPlan gp;
     const uint32_t n_ynum = numeric_yvals(P), n_guards = P.n_yvals - n_ynum;
     gp.pos.assign(n_guards, -1);
     gp.members.assign(n_guards, {});
-    const char *e_ = getenv("MARAY_JIT_DERIVED");
-    const bool derive = !(e_ && e_[0] == '0');
+    const bool derive = true;
     const RowTapeDeps d = row_tape_deps(P);
     std::vector<int32_t> src(n_guards, -1);                    // op that produces a guard's value
     std::unordered_map<int32_t, uint32_t> guard_of;            // op -> (first) guard it is the source of
@@ -537,8 +529,7 @@ RowChunks split_row_tape(const maray_program &P, const RowTapeDeps &d, uint32_t 
     std::sort(outs.begin(), outs.end(), [&](uint32_t x, uint32_t y) { return MARAY_INS_AUX(P.row_ops[x]) < MARAY_INS_AUX(P.row_ops[y]); });
     size_t total = 0;
     (void)row_tape_cone(P, d, outs, &total);
-    size_t per_chunk = 64;
-    if (const char *e_ = getenv("MARAY_JIT_ROW_CHUNK_OPS")) if (atoi(e_) > 0) per_chunk = (size_t)atoi(e_);      // tuning knob
+    const size_t per_chunk = 64;
     const uint32_t n_chunks = (uint32_t)std::min<size_t>(64, std::max<size_t>(std::max<size_t>(1, total / per_chunk), (outs.size() + ROW_CHUNK_MAX_OUTS - 1) / ROW_CHUNK_MAX_OUTS));
     const size_t budget = (total + n_chunks - 1) / n_chunks;
     RowChunks rc;
@@ -570,10 +561,7 @@ uint32_t jit_guard_words(const maray_program &P)
     return nw <= 1024 ? std::max(nw, 1u) : 0;       // 1024 words x 8 tiles = 64 KB of LDS
 }
 
-uint32_t jit_px();
-uint32_t jit_gw_inline_max();
-bool jit_coop();
-bool jit_persist();
+static const uint32_t GW_INLINE_MAX = 12;       // up to this many guard words a rectangle's words are named SGPR pairs; beyond, they stay one per lane (v_readlane per test)
 
 // The rectangle a guard is bounded over: `gh` rows x `gw` pixels.  gh = 1 (and gw = 256) when some guard's cone reads Y;
 // else every guard bounds its boolean over the rows [YMIN, YMAX] too (include/maray_tape.h) and the rectangle is the
@@ -583,36 +571,27 @@ bool jit_persist();
 // costs the ROW kernel nothing and spares the PIXEL kernel region entries.  Default 64 x 32 (chess @4096^2, frame / board
 // crop in us, 256 x 8: 49.3 / 104; 256 x 16: 48.9 / 104; 128 x 16: 45.1 / 92; 64 x 8: 49.0 / 83 -- four times the guard work;
 // 64 x 16: 45.5 / 84; 64 x 32: 43.8 / 84; 64 x 64: 45.1 / 86; 64 x 128: 48.1 / 88).  MARAY_JIT_GUARD_W = 64 / 128 / 256,
-// MARAY_JIT_GUARD_H = 8 ... 128: measurement knobs.  Narrow rectangles only in the default PIXEL layout with the
-// strip's words held one per lane.
+// MARAY_JIT_GUARD_H = 8 ... 128: measurement knobs.  A strip's words are held one per lane, so a tile's rectangles together
+// have to fit a wavefront's 64 lanes: a program with many guard words gets wider rectangles.
 GuardGeom jit_guard_geom(const maray_program &P)
 {
     GuardGeom g{256u, 1u};
     const uint32_t nw = jit_guard_words(P);
     if (!nw || any_guard_reads_y(P)) return g;
     g.gh = 32u;
-    if (const char *e_ = getenv("MARAY_JIT_GUARD_H")) { const int v = atoi(e_); if (v == 8 || v == 16 || v == 32 || v == 64 || v == 128) g.gh = (uint32_t)v; }
-    const char *env_gw = getenv("MARAY_JIT_GW");
-    const char *env_wide = getenv("MARAY_JIT_WIDE");       // (the whole section four pixels per lane tests a tile's bits once)
-    // narrow rectangles: the default PIXEL layout with a strip's words one per lane (<= 12 words per rectangle), or -- more
-    // words -- a tile's words one per lane: a tile's rectangles together then have to fit a wavefront's 64 lanes
-    const bool lanes = jit_px() == 4 && !jit_coop() && !jit_persist() && !(env_gw && !strcmp(env_gw, "sload")) && !(env_wide && env_wide[0] == '1');
+    const char *env_h = getenv("MARAY_JIT_GUARD_H");
+    if (env_h) { const int v = atoi(env_h); if (v == 8 || v == 16 || v == 32 || v == 64 || v == 128) g.gh = (uint32_t)v; }
     uint32_t want = 64u;
     if (const char *e_ = getenv("MARAY_JIT_GUARD_W")) { const int v = atoi(e_); if (v == 64 || v == 128 || v == 256) want = (uint32_t)v; }
-    while (want < 256u && !(lanes && nw * (256u / want) <= 64u)) want *= 2u;
-    if (want == 256u && !getenv("MARAY_JIT_GUARD_H")) g.gh = 8u;      // wide rectangles gain nothing from height (chess, 256 x 8 / 256 x 32: 48.6 / 50.2 us per frame)
+    while (want < 256u && nw * (256u / want) > 64u) want *= 2u;
+    if (want == 256u && !env_h) g.gh = 8u;      // wide rectangles gain nothing from height (chess, 256 x 8 / 256 x 32: 48.6 / 50.2 us per frame)
     g.gw = want;
     return g;
 }
 
 uint32_t jit_guard_rows(const maray_program &P) { return jit_guard_geom(P).gh; }
 
-// Threads per block of the ROW kernel (MARAY_JIT_ROW_BLOCK: 64 .. 1024, tuning knob; part of the generated source).
-unsigned jit_row_block()
-{
-    if (const char *e_ = getenv("MARAY_JIT_ROW_BLOCK")) if (atoi(e_) >= 64 && atoi(e_) <= 1024 && atoi(e_) % 64 == 0) return (unsigned)atoi(e_);
-    return 256;
-}
+static const unsigned ROW_BLOCK = 256;          // threads per block of the ROW kernel (64 ... 1024 move a chess frame by less than a microsecond)
 
 // Source of the ROW kernel, maray_jit_rows: one wavefront per block, blockIdx.y picks the job.
 //  y < n_chunks: chunk y of the ROW section, one work-item per row; writes the y values the pixel
@@ -638,7 +617,6 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
     // lengthens it (chess, step minus pixel kernel in us, regions kept from 0 / 12 / 24 / 60 / 200 instructions / none:
     // 7.2 / 6.9 / 6.3 / 6.8 / 8.3 / 8.3)
     E.min_region_row = 24;
-    if (const char *e_ = getenv("MARAY_JIT_ROW_MIN_REGION")) E.min_region_row = (uint32_t)atoi(e_);
     const uint32_t n_gjobs = n_gwords ? (plan.n_pos + 7) / 8 : 0;                // 8 bits = one byte of a word per job
     if (n_gjobs_out) *n_gjobs_out = n_gjobs;
     // the interpreter (which drains deferred tiles from the same y-value table) does read the guard values
@@ -650,9 +628,8 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
     s += "// generated by libmaray_hip (jit_backend.cpp): ROW section, " + std::to_string(P.n_row_ops) + " ops; y values in " +
          std::to_string(chunks.size()) + " chunks, " + std::to_string(P.n_yvals - n_ynum) + " guards in " + std::to_string(n_gwords) + " words\n";
     s += "#include \"device_math.h\"\n\n";
-    const char *env_rw = getenv("MARAY_JIT_ROW_WAVES");          // tuning knob: occupancy hint of the ROW kernel
-    const unsigned row_block = jit_row_block();
-    s += "extern \"C\" __global__ void __launch_bounds__(" + std::to_string(row_block) + (env_rw ? ", " + std::string(env_rw) : std::string()) + ") maray_jit_rows(double *__restrict__ yvals, unsigned long long *__restrict__ gbits,\n"
+    const unsigned row_block = ROW_BLOCK;
+    s += "extern \"C\" __global__ void __launch_bounds__(" + std::to_string(row_block) + ") maray_jit_rows(double *__restrict__ yvals, unsigned long long *__restrict__ gbits,\n"
          "                                                                 const MarayTex *__restrict__ tex,\n"
          "                                                                 unsigned y0, unsigned rows, unsigned n_yvals, unsigned w, unsigned n_tx,\n"
          "                                                                 unsigned blk_rows, unsigned blk_stride, unsigned yrows)\n{\n"
@@ -661,7 +638,7 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
          "    // guard jobs first in the grid (they are the long ones: the y-value jobs fill in behind them): job = the switch index\n"
          "    const unsigned mr_job = blockIdx.y < " + std::to_string(n_gjobs) + "u ? " + std::to_string(chunks.size()) + "u + blockIdx.y : blockIdx.y - " + std::to_string(n_gjobs) + "u;\n"
          "    if (mr_job < " + std::to_string(chunks.size()) + "u) {\n"
-         + std::string(getenv("MARAY_JIT_ROW_PART") && (getenv("MARAY_JIT_ROW_PART")[0] == '2' || getenv("MARAY_JIT_ROW_PART")[0] == '3') ? "    return;      // measurement: guard jobs only (wrong pixels!)\n" : "") +
+         +
          "    // y values: a work-item per row.  A lane's values go to LDS ([value][row], values 68 apart) and leave as rows of the\n"
          "    // table, a chunk's values side by side: full cache lines.  Stored from the registers, a\n"
          "    // wavefront's store touches 64 lines for 8 bytes each -- 1.2 M partial writes per frame, which is what the kernel\n"
@@ -696,7 +673,6 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
          "    }\n"
          "    return;\n    }\n";
     if (n_gwords) {
-        if (getenv("MARAY_JIT_ROW_PART") && (getenv("MARAY_JIT_ROW_PART")[0] == '1' || getenv("MARAY_JIT_ROW_PART")[0] == '3')) s += "    return;      // measurement: y-value jobs only (wrong pixels!)\n";
         s += "    // guards: (row group, tile), the tiles of a group adjacent\n"
              "    const unsigned n_groups = (rows + yrows - 1u) / yrows;\n"
              "    if (item >= n_groups * n_tx) return;\n"
@@ -757,27 +733,10 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
     return s;
 }
 
-// Pixels per lane of the specialised PIXEL kernel: 4 (default; a wavefront owns a 256-pixel tile) or 1 (the first
-// layout: a wavefront owns 64 pixels, a block stages its tiles' guard words in LDS; MARAY_JIT_PX=1, kept as an ablation).
-uint32_t jit_px()
-{
-    const char *e_ = getenv("MARAY_JIT_PX");
-    return (e_ && e_[0] == '1') ? 1u : 4u;
-}
-
-// Up to this many guard words a tile's words are named SGPR pairs (wave layout); beyond, they stay one per lane and a
-// test takes its word with v_readlane.  MARAY_JIT_GW_MANY=1 (tests): the second form whatever the count.
-uint32_t jit_gw_inline_max()
-{
-    const char *e_ = getenv("MARAY_JIT_GW_MANY");
-    return (e_ && e_[0] == '1') ? 0u : 12u;
-}
-
 // The general section four pixels per lane: only a short program without guards whose ops are single instructions (no libm
-// bodies, no gathers).  MARAY_JIT_WIDE=0/1: never / always (measurement knob).
+// bodies, no gathers).
 bool jit_wide_general(const maray_program &P)
 {
-    if (const char *e_ = getenv("MARAY_JIT_WIDE")) return e_[0] == '1';
     bool heavy = false;
     for (uint32_t i = 0; i < P.n_pix_ops; i++) {
         const uint32_t op = MARAY_INS_OP(P.pix_ops[i]);
@@ -786,45 +745,35 @@ bool jit_wide_general(const maray_program &P)
     return jit_guard_words(P) == 0 && !heavy && P.n_pix_slots <= 6 && P.n_pix_ops <= 256;
 }
 
-// Which wavefronts take a tile where shapes may show: one wavefront in four passes of 64 pixels (default), or the block's
-// four side by side, one 64-pixel run each (MARAY_JIT_LAYOUT=coop: every wavefront then walks every tile of the strip,
-// and a strip of sky costs what it did with one pixel per lane: chess 48.5 against 44.4 us per frame, measured).
-bool jit_coop()
-{
-    const char *e_ = getenv("MARAY_JIT_LAYOUT");
-    return e_ && !strcmp(e_, "coop");
-}
-
-// One wavefront per strip (default), or persistent wavefronts walking (row, strip) items at a stride (MARAY_JIT_PERSIST=1:
-// measured slower -- chess 55.9 against 44.1 us per frame, board 136 against 105: the loop-carried item state pushes the
-// kernel past its 102 SGPRs (322 spills) and a wavefront's items are no longer neighbours in the caches).
-bool jit_persist()
-{
-    const char *e_ = getenv("MARAY_JIT_PERSIST");
-    return !jit_coop() && e_ && e_[0] == '1';
-}
-
-// Source of the PIXEL kernel (default layout).  A block of four wavefronts owns `tiles` consecutive 256-pixel tiles
-// of one row (blockIdx.y) and walks them without staging or barriers: every wavefront reads a tile's guard words by
-// scalar loads and one scalar test picks the tile's variant:
+// Source of the PIXEL kernel, maray_jit_pixels.  A wavefront owns a strip of `tiles` consecutive 256-pixel tiles of one
+// row (blockIdx.y); a block is four wavefronts = four neighbouring strips that share nothing but the instruction cache:
+// no staging, no barrier.  The strip's guard words arrive with one vector load (lane i = word i); per tile one scalar
+// test of a ballot picks the variant:
 //
-//  * WIDE, four pixels per lane (device_math.h, MR_VEC4: every value four f64, every boolean four lane masks), ONE
-//    wavefront for the whole tile (such tiles are dealt to the block's four wavefronts in turn).  The variant of a tile
-//    none of whose guard bits is set (every guarded region is the literal 0: for chess the background, one multiply),
-//    and the whole section of a small program without guards (config 2: six ops).  The scalar unit's share of a tile
-//    and the store's address arithmetic are paid once per 256 pixels, and a lane's four RGB8 pixels are 12 contiguous
-//    bytes: one global_store_dwordx3, no cross-lane packing.  This is the path that is bound by the store (3 B per
-//    pixel) and little else: a frame of nothing but sky went 22.7 -> 13 us.
-//  * NARROW, one pixel per lane, the four wavefronts side by side on the tile's four 64-pixel runs.  The variant of a
+//  * WIDE, four pixels per lane (device_math.h, MR_VEC4: every value four f64, every boolean four lane masks).  The
+//    variant of a tile none of whose guard bits is set (every guarded region is the literal 0: for chess the background,
+//    one multiply), and the whole section of a small program without guards (config 2: six ops).  The scalar unit's
+//    share of a tile and the store's address arithmetic are paid once per 256 pixels, and a lane's four RGB8 pixels are
+//    12 contiguous bytes: one global_store_dwordx3, no cross-lane packing.  This is the path that is bound by the store
+//    (3 B per pixel) and little else.
+//  * NARROW, one pixel per lane, four passes of 64 pixels (a loop: the section's code exists once).  The variant of a
 //    tile where shapes may show.  Regions are entered per 64 pixels, where a wave-level SKIP op still finds all lanes
-//    agreeing; values are single f64 (chess: 20 VGPRs); the four wavefronts walk the same regions at the same time
-//    and share their instruction fetches.  (Carried four wide the same section needs 105 VGPRs, spills a thousand
-//    SGPRs and runs the board 1.5x slower; one wavefront doing the four runs in turn, 1.15x slower: measured.)
+//    agreeing; values are single f64.  The passes leave their packed pixels in LDS (same-wave traffic: no barrier) and
+//    the tile is stored like a wide one.
 //
 // When f64 planes are wanted too, element e of a wide lane l is pixel x0 + 64 e + l and every 64-pixel run is stored on
-// its own (24 B per lane, the coalesced pattern of the f64 planes).
-static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
+// its own (24 B per lane, the coalesced pattern of the f64 planes).  A Sin whose argument is huge (|x| >= 105414350), inf
+// or NaN does not call the slow reduction here (a call site per Sin op would force every live value through scratch): the
+// tile is flagged instead and re-evaluated by the tape interpreter kernel afterwards, so the final raster is identical.
+// Layouts that were measured and lost (a wavefront per 64 pixels with guard words staged in LDS, a busy tile on the
+// block's four wavefronts side by side, persistent wavefronts, two pixels per lane, guard words by scalar loads, a
+// sky loop of its own ...) are history: DESIGN.md section 7.1, profiles/r2_ablations.jsonl.
+std::string jit_source(const maray_program &P, int min_waves)
 {
+    validate_program(P);
+    // 6 waves per SIMD, i.e. up to 102 SGPRs (at 8 the compiler gets 76 and spills ~400 of them to VGPR lanes, in the skeleton
+    // of bit tests and branches every pass walks; chess needs 38 VGPRs either way and runs 7 waves per SIMD)
+    if (min_waves == 0) min_waves = 6;
     Emitter E(P);
     // Wave-level SKIP ops over fewer than 12 instructions' worth of ops are ignored: a busy tile is bound by the scalar unit
     // (branches, bit tests, mask algebra: 0.59 SALU instructions per cycle and CU against 35 % VALU issue), and a short
@@ -834,9 +783,8 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
     E.min_region = 12;
     if (const char *e_ = getenv("MARAY_JIT_MIN_REGION")) E.min_region = (uint32_t)atoi(e_);
     E.ybool = jit_bool_yvals(P);
+    E.ktab = true;
     std::string &s = E.out;
-    const char *env_waves = getenv("MARAY_JIT_WAVES");
-    const int min_waves = env_waves ? atoi(env_waves) : min_waves_arg;
     const uint32_t n_ynum = numeric_yvals(P);
     const uint32_t n_gwords = jit_guard_words(P);
     E.ignore_row_guards = n_gwords == 0;
@@ -844,27 +792,23 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
     const GuardGeom geom = jit_guard_geom(P);
     const uint32_t sub = 256u / geom.gw;                   // guard rectangles per 256-pixel tile (> 1: their words are taken per pass)
     const std::string tw = std::to_string(sub * n_gwords);  // guard words per tile
-    const uint32_t gw_max = jit_gw_inline_max();
-    if (n_gwords) { E.guard_first = n_ynum; E.guard_words = n_gwords; E.plan = &plan; E.gw_lanes = true; E.gw_inline_max = gw_max; }
+    if (n_gwords) { E.guard_first = n_ynum; E.guard_words = n_gwords; E.plan = &plan; E.gw_inline_max = GW_INLINE_MAX; }
     const bool defer = may_defer_tiles(P);
     const std::string nw = std::to_string(n_gwords);
-    const bool coop = jit_coop();
-    const bool persist = jit_persist();
-    // a strip's guard words: one vector load per wavefront (lane i holds word i), then v_readlane per tile -- one memory
-    // latency per strip instead of one per tile (MARAY_JIT_GW=sload: scalar loads per tile; measurement knob)
-    const char *env_gw = getenv("MARAY_JIT_GW");
-    const bool gw_vgpr = n_gwords && n_gwords <= gw_max && !(env_gw && !strcmp(env_gw, "sload"));
+    // a strip's guard words: one vector load per wavefront (lane i holds word i), then v_readlane per tile or pass -- one
+    // memory latency per strip instead of one per tile
+    const bool gw_vgpr = n_gwords && n_gwords <= GW_INLINE_MAX;
     const bool wide_general = jit_wide_general(P);
+    const std::string esub = "(e >> " + std::to_string(sub == 4 ? 0 : 1) + "u)";       // rectangle of pass e inside its tile
     s += "// generated by libmaray_hip (jit_backend.cpp) from a v" + std::to_string(P.version) + " tape: PIXEL section, " +
-         std::to_string(P.n_pix_ops) + " ops; general variant " + (wide_general ? "four pixels per lane, a wavefront per tile" : "one pixel per lane, four wavefronts per tile") + "\n"
+         std::to_string(P.n_pix_ops) + " ops; general variant " + (wide_general ? "four pixels per lane" : "one pixel per lane, four passes per tile") + "\n"
          "#define MR_VEC4 1\n"
          "__shared__ unsigned mr_slow[4];           // per wavefront: some Sin of the tile at hand needs the slow path\n"
-         + std::string(coop ? "" : "__shared__ unsigned mr_tp[4 * 256];       // per wavefront: the packed pixels of a tile's four passes\n") +
+         "__shared__ unsigned mr_tp[4 * 256];       // per wavefront: the packed pixels of a tile's four passes\n"
          "__device__ inline double mr_defer_sin(double) { ((volatile unsigned *)mr_slow)[threadIdx.x >> 6] = 1u; return 0.0; }\n"
          "#define MR_SIN_HUGE(x) mr_defer_sin(x)   // plain Sin ops: flag the tile from the (rare) branch\n"
          "#include \"device_math.h\"\n"
          "typedef const __attribute__((address_space(4))) double *mr_kptr;\n"
-         "typedef const __attribute__((address_space(4))) unsigned long long *mr_gptr;\n"
          "struct __attribute__((aligned(4))) mr_u3 { unsigned a, b, c; };\n"
          "struct __attribute__((aligned(16))) mr_u4 { unsigned a, b, c, d; };\n"
          "__device__ inline mr_mask mr_lane64(unsigned long long v, unsigned lane)      // lane `lane` (wave-uniform) of a per-lane 64-bit value -> SGPR pair\n"
@@ -872,36 +816,22 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
          "    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, (int)lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), (int)lane);\n"
          "    return ((mr_mask)hi << 32) | lo;\n"
          "}\n/*MR_KTAB*/\n";
-    s += "extern \"C\" __global__ void __launch_bounds__(256" + (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string()) +
+    s += "extern \"C\" __global__ void __launch_bounds__(256, " + std::to_string(min_waves) +
          ") maray_jit_pixels(unsigned char *__restrict__ rgb8, double *__restrict__ rgb64,\n"
          "                                                                    const double *__restrict__ yvals, const MarayTex *__restrict__ tex,\n"
          "                                                                    unsigned *__restrict__ tile_list, unsigned tile_base,\n"
          "                                                                    const unsigned long long *__restrict__ gbits, unsigned n_tx,\n"
          "                                                                    unsigned w, unsigned y0, unsigned n_yvals, unsigned tiles,\n"
          "                                                                    unsigned blk_rows, unsigned blk_stride, unsigned row_base, unsigned yrows,\n"
-         "                                                                    const unsigned *__restrict__ row_order, unsigned rows, unsigned strip_shift, unsigned swz)\n{\n"
+         "                                                                    const unsigned *__restrict__ row_order)\n{\n"
          "    const unsigned mr_wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), mr_lane = threadIdx.x & 63u;\n"
-         "    (void)rows; (void)strip_shift; (void)swz;\n"
-         + std::string(persist ?
-           "    // Persistent wavefronts: the grid fills the device once and every wavefront walks the (row, strip) items w, w + W,\n"
-           "    // w + 2 W, ... of the launch, rows in launch order (dearest groups first): each wavefront meets every price band,\n"
-           "    // the launch ends on cheap items, and a wavefront's start-up and the drain of its stores are paid once, not per strip.\n"
-           "    const unsigned mr_strips = (n_tx + tiles - 1u) / tiles, mr_items = rows * mr_strips;\n"
-           "    for (unsigned mr_item = blockIdx.x * 4u + mr_wv; mr_item < mr_items; mr_item += gridDim.x * 4u) {\n"
-           "    const unsigned mr_slot = strip_shift != 0xffffffffu ? mr_item >> strip_shift : mr_item / mr_strips;\n"
-           "    const unsigned tile0 = (mr_item - mr_slot * mr_strips) * tiles;          // this item's strip of its row\n"
-           "    const unsigned r = row_order ? row_order[mr_slot] : mr_slot;             // row of this launch; row_base + r = row of the whole call\n"
-           : (coop ? "    const unsigned tile0 = blockIdx.x * tiles;                              // this block's strip of the row\n"
-                   : "    // Workgroups go to the 8 XCDs round robin by their linear id, blockIdx.y * gridDim.x + blockIdx.x: with 2, 4 or 8\n"
-                     "    // blocks per row a column of the image would always meet the same XCDs, and a scene that is busier on one side\n"
-                     "    // would load them unevenly.  So a row's blocks take its strips rotated by the row (swz = gridDim.x - 1 when that\n"
-                     "    // is a power of two, else 0).\n"
-                     "    const unsigned tile0 = ((((blockIdx.x + blockIdx.y) & swz) | (blockIdx.x & ~swz)) * 4u + mr_wv) * tiles;               // this wavefront's strip of the row\n")) +
-         (persist ? "" :
+         "    // (workgroups go to the 8 XCDs round robin by their linear id: with 2, 4 or 8 blocks per row a column of the image\n"
+         "    // always meets the same XCDs; rotating a row's strips by the row was measured and is not worth it, DESIGN.md 7.1)\n"
+         "    const unsigned tile0 = (blockIdx.x * 4u + mr_wv) * tiles;               // this wavefront's strip of the row\n"
          "    if (tile0 >= n_tx) return;\n"
-         "    const unsigned r = row_order ? row_order[blockIdx.y] : blockIdx.y;     // row of this launch (dearest groups of rows first); row_base + r = row of the whole call\n") +
+         "    const unsigned r = row_order ? row_order[blockIdx.y] : blockIdx.y;     // row of this launch (dearest groups of rows first); row_base + r = row of the whole call\n"
          "    const unsigned long long mr_ybase0 = (unsigned long long)(yvals + (size_t)r * n_yvals);\n"
-         "    // -> image row (RowBlocks); one range of rows (blk_stride == 0) needs no division, and yrows is 1 or 8\n"
+         "    // -> image row (RowBlocks); one range of rows (blk_stride == 0) needs no division, and yrows is a power of two\n"
          "    const double Y = (double)(blk_stride == 0u ? y0 + row_base + r : y0 + ((row_base + r) / blk_rows) * blk_stride + (row_base + r) % blk_rows);\n"
          "    (void)Y; (void)tex; (void)gbits; (void)yrows; (void)tile_list; (void)tile_base;\n";
     if (n_gwords)
@@ -914,47 +844,25 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
          "    const unsigned mr_xl = mr_wide ? 4u * mr_lane : mr_lane, mr_xs = mr_wide ? 1u : 64u;\n"
          "    const unsigned mr_src = (mr_lane * 4u) / 3u, mr_shift = ((mr_lane * 4u) % 3u) * 8u;   // RGB8 packing of one 64-pixel run\n"
          "    const size_t row_px = (size_t)r * w;\n"
-         "    unsigned mr_dealt = 0u;                                                  // tiles of this strip that went to ONE wavefront so far\n";
-    const size_t head_begin = s.size();              // the head of the loop over the strip's tiles (emitted again by the two-loop form below)
-    s += "    for (unsigned t = 0; t < tiles; t++) {\n"
+         "    for (unsigned t = 0; t < tiles; t++) {\n"
          "    const unsigned x0 = (tile0 + t) * 256u;\n"
          "    if (x0 >= w) break;\n"
-
          "    // y values, constants, guard words: scalar loads where they are used, from addresses made opaque in every trip (fresh\n"
          "    // copies: an asm output carried around the loop counts as divergent once a lane-dependent branch sits in the loop)\n"
          "/*MR_KBASE*/";
-    if (n_gwords) {
-        if (!gw_vgpr)
-            s += "    unsigned long long mr_gbase = mr_gbase0;\n"
-                 "    asm volatile(\"\" : \"+s\"(mr_gbase));\n"
-                 "    const mr_gptr mr_gk = (mr_gptr)mr_gbase + t * " + nw + "u;\n";
-        if (gw_vgpr && sub > 1) ;            // narrow rectangles: a pass takes the words of its own rectangle
-        else if (gw_vgpr)
-            for (uint32_t j = 0; j < n_gwords; j++)
-                s += "    mr_mask gq" + std::to_string(j) + " = mr_lane64(mr_gv, t * " + nw + "u + " + std::to_string(j) + "u);\n";
-        else if (n_gwords <= gw_max)
-            for (uint32_t j = 0; j < n_gwords; j++)
-                s += "    mr_mask gq" + std::to_string(j) + " = mr_gk[" + std::to_string(j) + "u];\n";
-        else if (sub > 1)   // many words, narrow rectangles: lane i of mr_gt0 holds word i of the tile's rectangles (<= 64 together, jit_guard_geom)
+    if (n_gwords && !gw_vgpr) {
+        s += "    unsigned long long mr_gbase = mr_gbase0;\n"
+             "    asm volatile(\"\" : \"+s\"(mr_gbase));\n";
+        if (sub > 1)   // many words, narrow rectangles: lane i of mr_gt0 holds word i of the tile's rectangles (<= 64 together, jit_guard_geom)
             s += "    unsigned long long mr_gt0 = mr_lane < " + tw + "u ? ((const unsigned long long *)mr_gbase)[t * " + tw + "u + mr_lane] : 0ull;\n";
-        else        // many words: lane i of mr_gt<j> holds word 64 j + i of this tile (one vector load each); a test takes its word with v_readlane
+        else           // lane i of mr_gt<j> holds word 64 j + i of this tile (one vector load each); a test takes its word with v_readlane
             for (uint32_t j = 0; j < (n_gwords + 63) / 64; j++)
                 s += "    unsigned long long mr_gt" + std::to_string(j) + " = " + std::to_string(64 * j) + "u + mr_lane < " + nw + "u ? ((const unsigned long long *)mr_gbase)[t * " + nw + "u + " +
                      std::to_string(64 * j) + "u + mr_lane] : 0ull;\n";
-    }
+    } else if (gw_vgpr && sub == 1)
+        for (uint32_t j = 0; j < n_gwords; j++)
+            s += "    mr_mask gq" + std::to_string(j) + " = mr_lane64(mr_gv, t * " + nw + "u + " + std::to_string(j) + "u);\n";
     if (defer) s += "    ((volatile unsigned *)mr_slow)[mr_wv] = 0u;\n    bool mr_slow_tile = false;\n";
-    const std::string loop_head = s.substr(head_begin);
-    // Two loops over the strip instead of one (MARAY_JIT_TWO_LOOPS=1): first the tiles with no guard bit set, then -- if the
-    // strip has any -- the others.  What the back end hoists out of the busy variant (constants of its libm bodies) then
-    // lands in front of the second loop, which a wavefront of sky never reaches, instead of in every wavefront's prologue.
-    const char *env_tl = getenv("MARAY_JIT_TWO_LOOPS");
-    const bool two_loops = gw_vgpr && sub > 1 && !coop && !persist && !wide_general && env_tl && env_tl[0] == '1';
-    // =2: a strip with no guard bit at all takes a loop of its own (the wide variant only), any other strip the one loop
-    // with both variants: the busy strips run the code they always ran
-    const bool sky_strips = gw_vgpr && sub > 1 && !coop && !persist && !wide_general && env_tl && env_tl[0] == '2';
-    std::string wide_block;
-    // a tile for one wavefront: the block's four take such tiles in turn
-    const std::string deal = coop ? "    const bool mr_mine = (mr_dealt & 3u) == mr_wv;\n    mr_dealt++;\n    if (mr_mine) {\n" : "    {\n";
     if (!E.ignore_row_guards) {         // dry run: which ops yield lane masks
         Emitter D(P);
         D.ignore_row_guards = true;
@@ -962,10 +870,6 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
         D.ybool = E.ybool;
         D.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
         E.bool_hint = D.is_bool_op;
-    }
-    {
-        const char *e_ = getenv("MARAY_JIT_KTAB");
-        E.ktab = !(e_ && e_[0] == '0');
     }
     // what opens a pass of either width: the tables made opaque (LICM would hoist every constant and y value out of the
     // loops and spill them), the pixel coordinates, the outputs
@@ -975,27 +879,23 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
         "    mr_kptr yv = (mr_kptr)mr_ybase;\n"
         "    const __attribute__((address_space(4))) unsigned *yw = (const __attribute__((address_space(4))) unsigned *)yv;\n"
         "    (void)yv; (void)yw;\n/*MR_KC*/";
-    // the tile's guard words, opaque anew in every pass: left visible, all their bit tests are loop invariants too
-    // (168 booleans for chess, hoisted and spilled to VGPR lanes)
+    // the guard words of the rectangle at hand, opaque anew in every pass: left visible, all their bit tests are loop
+    // invariants too (168 booleans for chess, hoisted and spilled to VGPR lanes)
     std::string gq_pass;
-    if (n_gwords > gw_max && sub > 1) {
+    if (n_gwords && !gw_vgpr && sub > 1) {
         gq_pass = "    asm volatile(\"\" : \"+v\"(mr_gt0));\n"
-                  "    const unsigned mr_gsub = (e >> " + std::to_string(sub == 4 ? 0 : 1) + "u) * " + nw + "u;           // first word of this pass's rectangle\n";
+                  "    const unsigned mr_gsub = " + esub + " * " + nw + "u;           // first word of this pass's rectangle\n";
         E.gw_lane_base = "mr_gsub";
-    } else if (n_gwords && sub > 1)
+    } else if (gw_vgpr && sub > 1)
         for (uint32_t j = 0; j < n_gwords; j++) {
             const std::string k = std::to_string(j);
-            gq_pass += "    mr_mask gq" + k + " = mr_lane64(mr_gv, (t * " + std::to_string(sub) + "u + (e >> " + std::to_string(sub == 4 ? 0 : 1) + "u)) * " + nw + "u + " + k + "u);\n"
+            gq_pass += "    mr_mask gq" + k + " = mr_lane64(mr_gv, (t * " + std::to_string(sub) + "u + " + esub + ") * " + nw + "u + " + k + "u);\n"
                        "    asm volatile(\"\" : \"+s\"(gq" + k + "));\n";
         }
-    else if (n_gwords && n_gwords <= gw_max)
-        for (uint32_t j = 0; j < n_gwords; j++) {
-            const std::string k = std::to_string(j);
-            gq_pass += "    asm volatile(\"\" : \"+s\"(gq" + k + "));\n";
-        }
+    else if (gw_vgpr)
+        for (uint32_t j = 0; j < n_gwords; j++) gq_pass += "    asm volatile(\"\" : \"+s\"(gq" + std::to_string(j) + "));\n";
     else if (n_gwords)
-        for (uint32_t j = 0; j < (n_gwords + 63) / 64; j++)
-            gq_pass += "    asm volatile(\"\" : \"+v\"(mr_gt" + std::to_string(j) + "));\n";
+        for (uint32_t j = 0; j < (n_gwords + 63) / 64; j++) gq_pass += "    asm volatile(\"\" : \"+v\"(mr_gt" + std::to_string(j) + "));\n";
     const std::string wide_open =
         "    {\n" + opaque + (sub > 1 ? std::string() : gq_pass) +
         "    const unsigned xa = x0 + mr_xl;                                        // this lane's first pixel\n"
@@ -1056,11 +956,11 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
 
     if (n_gwords) {
         // the variant of a tile with no guard bit set, four pixels per lane
-        if (sub > 1 && n_gwords > gw_max)
+        if (!gw_vgpr && sub > 1)
             s += "    if (mr_ballot(mr_gt0 != 0ull) == 0ull) {\n";
         else if (sub > 1)
             s += "    if (((mr_gnz >> (t * " + tw + "u)) & " + std::to_string((1ull << (sub * n_gwords)) - 1ull) + "ull) == 0ull) {\n";
-        else if (n_gwords <= gw_max) {
+        else if (gw_vgpr) {
             std::string any = "gq0";
             for (uint32_t j = 1; j < n_gwords; j++) any += " | gq" + std::to_string(j);
             s += "    if ((" + any + ") == 0ull) {\n";
@@ -1071,108 +971,46 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
         }
         E.td = "mr_d"; E.tm = "mr_m";
         E.assume_guards_zero = true;
-        const size_t wide_begin = s.size();
-        s += deal + wide_open;
+        s += wide_open;
         E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
         s += wide_close;
         E.assume_guards_zero = false;
-        wide_block = s.substr(wide_begin) + tile_end + "    }\n";
-        if (two_loops) {
-            std::string zero = "((mr_gnz >> (t * " + tw + "u)) & " + std::to_string((1ull << (sub * n_gwords)) - 1ull) + "ull) == 0ull";
-            s += tile_end + "    }\n    }\n    }\n"                                     // ... the wide block, `if (no bit set)`, the first loop
-                 "    if (mr_gnz != 0ull) {\n" + loop_head +
-                 "    if (" + zero + ") continue;\n";
-        } else
-        s += tile_end + "    }\n    continue;\n    }\n";
+        s += tile_end + "    continue;\n    }\n";
     }
     if (wide_general) {
         E.td = "mr_d"; E.tm = "mr_m";
-        s += deal + wide_open;
+        s += wide_open;
         E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
-        s += wide_close + tile_end + "    }\n";
+        s += wide_close + tile_end;
     } else {
+        // one wavefront, four passes of 64 pixels (a loop, not unrolled); the passes leave their packed pixels in LDS
+        // (same-wave traffic: no barrier) and a whole aligned tile is stored as a dwordx3 per lane
         E.td = "double"; E.tm = "mr_mask";
-        if (coop) {
-            s += "    {                                                                       // this wavefront's 64-pixel run of the tile\n" + opaque + gq_pass +
-                 "    const unsigned xw = x0 + 64u * mr_wv, x = xw + mr_lane;\n"
-                 "    const double X = (double)x;\n"
-                 "    double o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"
-                 "    float mr_defer = 0.0f;\n"
-                 "    (void)X; (void)mr_defer;\n";
-            E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
-            s += defer_pass +
-                 "    const unsigned pk = mr_cast_u8(o0) | (mr_cast_u8(o1) << 8) | (mr_cast_u8(o2) << 16);\n"
-                 "    mr_store_run(rgb8, rgb64, row_px, xw, w, mr_lane, mr_src, mr_shift, pk, o0, o1, o2);\n"
-                 "    }\n" + tile_end;
-        } else {
-            // one wavefront, four passes of 64 pixels (a loop, not unrolled); the passes leave their packed pixels in LDS
-            // (same-wave traffic: no barrier) and a whole aligned tile is stored as a dwordx3 per lane.
-            // MARAY_JIT_NARROW=2: two passes of 128 pixels, two pixels per lane (measurement knob).
-            const char *env_nw = getenv("MARAY_JIT_NARROW");
-            const bool two = env_nw && env_nw[0] == '2' && sub == 1;
-            if (two) { E.td = "mr_d2"; E.tm = "mr_m2"; }
-            s += "    const bool mr_fast = rgb8 && x0 + 256u <= w && ((size_t)(rgb8 + (row_px + x0) * 3) & 3u) == 0u;      // wave-uniform\n"
-                 "    _Pragma(\"unroll 1\") for (unsigned e = 0; e < " + std::string(two ? "2u" : "4u") + "; e++) {\n" + opaque + gq_pass +
-                 (two ? "    const unsigned xw = x0 + 128u * e, x = xw + mr_lane;\n"
-                        "    const mr_d2 X((double)x, (double)(x + 64u));\n"
-                        "    mr_d2 o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"
-                      : "    const unsigned xw = x0 + 64u * e, x = xw + mr_lane;\n"
-                        "    const double X = (double)x;\n"
-                        "    double o0 = 0.0, o1 = 0.0, o2 = 0.0;\n") +
-                 "    float mr_defer = 0.0f;\n"
-                 "    (void)X; (void)mr_defer;\n";
-            const char *env_ps = getenv("MARAY_JIT_PASS_SKY");
-            const bool pass_sky = sub > 1 && n_gwords <= gw_max && env_ps && env_ps[0] == '1';       // measured: no gain (chess 36.5 against 36.1 us), off
-            if (pass_sky) {
-                // a pass none of whose rectangle's guard bits is set (the tile's other passes have some): the section with every
-                // guarded region the literal 0, instead of a walk through the skeleton of bit tests that all fail
-                std::string any = "gq0";
-                for (uint32_t j = 1; j < n_gwords; j++) any += " | gq" + std::to_string(j);
-                s += "    if ((" + any + ") == 0ull) {\n";
-                E.assume_guards_zero = true;
-                E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
-                E.assume_guards_zero = false;
-                s += "    } else {\n";
-            }
-            E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
-            if (pass_sky) s += "    }\n";
-            E.td = "double"; E.tm = "mr_mask";
-            s += defer_pass;
-            if (two)
-                s += "    const unsigned pka = mr_cast_u8(o0.a) | (mr_cast_u8(o1.a) << 8) | (mr_cast_u8(o2.a) << 16);\n"
-                     "    const unsigned pkb = mr_cast_u8(o0.b) | (mr_cast_u8(o1.b) << 8) | (mr_cast_u8(o2.b) << 16);\n"
-                     "    if (mr_fast) {\n"
-                     "        mr_tp[mr_wv * 256u + 128u * e + mr_lane] = pka;\n"
-                     "        mr_tp[mr_wv * 256u + 128u * e + 64u + mr_lane] = pkb;\n"
-                     "        mr_store_run(nullptr, rgb64, row_px, xw, w, mr_lane, mr_src, mr_shift, pka, o0.a, o1.a, o2.a);\n"
-                     "        mr_store_run(nullptr, rgb64, row_px, xw + 64u, w, mr_lane, mr_src, mr_shift, pkb, o0.b, o1.b, o2.b);\n"
-                     "    } else {\n"
-                     "        mr_store_run(rgb8, rgb64, row_px, xw, w, mr_lane, mr_src, mr_shift, pka, o0.a, o1.a, o2.a);\n"
-                     "        mr_store_run(rgb8, rgb64, row_px, xw + 64u, w, mr_lane, mr_src, mr_shift, pkb, o0.b, o1.b, o2.b);\n"
-                     "    }\n";
-            else
-                s += "    const unsigned pk = mr_cast_u8(o0) | (mr_cast_u8(o1) << 8) | (mr_cast_u8(o2) << 16);\n"
-                     "    if (mr_fast) {\n"
-                     "        mr_tp[mr_wv * 256u + 64u * e + mr_lane] = pk;\n"
-                     "        mr_store_run(nullptr, rgb64, row_px, xw, w, mr_lane, mr_src, mr_shift, pk, o0, o1, o2);\n"
-                     "    } else mr_store_run(rgb8, rgb64, row_px, xw, w, mr_lane, mr_src, mr_shift, pk, o0, o1, o2);\n";
-            s += "    }\n"
-                 "    if (mr_fast) {\n"
-                 "        __builtin_amdgcn_wave_barrier();                                     // same wavefront wrote them: LDS keeps its order\n"
-                 "        const mr_u4 p = *(const mr_u4 *)&mr_tp[mr_wv * 256u + 4u * mr_lane];\n"
-                 "        mr_u3 d;\n"
-                 "        d.a = p.a | (p.b << 24); d.b = (p.b >> 8) | (p.c << 16); d.c = (p.c >> 16) | (p.d << 8);\n"
-                 "        *(mr_u3 *)(rgb8 + (row_px + x0 + 4u * mr_lane) * 3) = d;\n"
-                 "        __builtin_amdgcn_wave_barrier();\n"
-                 "    }\n" + tile_end;
-        }
+        s += "    const bool mr_fast = rgb8 && x0 + 256u <= w && ((size_t)(rgb8 + (row_px + x0) * 3) & 3u) == 0u;      // wave-uniform\n"
+             "    _Pragma(\"unroll 1\") for (unsigned e = 0; e < 4u; e++) {\n" + opaque + gq_pass +
+             "    const unsigned xw = x0 + 64u * e, x = xw + mr_lane;\n"
+             "    const double X = (double)x;\n"
+             "    double o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"
+             "    float mr_defer = 0.0f;\n"
+             "    (void)X; (void)mr_defer;\n";
+        E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+        s += defer_pass +
+             "    const unsigned pk = mr_cast_u8(o0) | (mr_cast_u8(o1) << 8) | (mr_cast_u8(o2) << 16);\n"
+             "    if (mr_fast) {\n"
+             "        mr_tp[mr_wv * 256u + 64u * e + mr_lane] = pk;\n"
+             "        mr_store_run(nullptr, rgb64, row_px, xw, w, mr_lane, mr_src, mr_shift, pk, o0, o1, o2);\n"
+             "    } else mr_store_run(rgb8, rgb64, row_px, xw, w, mr_lane, mr_src, mr_shift, pk, o0, o1, o2);\n"
+             "    }\n"
+             "    if (mr_fast) {\n"
+             "        __builtin_amdgcn_wave_barrier();                                     // same wavefront wrote them: LDS keeps its order\n"
+             "        const mr_u4 p = *(const mr_u4 *)&mr_tp[mr_wv * 256u + 4u * mr_lane];\n"
+             "        mr_u3 d;\n"
+             "        d.a = p.a | (p.b << 24); d.b = (p.b >> 8) | (p.c << 16); d.c = (p.c >> 16) | (p.d << 8);\n"
+             "        *(mr_u3 *)(rgb8 + (row_px + x0 + 4u * mr_lane) * 3) = d;\n"
+             "        __builtin_amdgcn_wave_barrier();\n"
+             "    }\n" + tile_end;
     }
-    if (sky_strips && !wide_block.empty()) {
-        // (the busy strips' loop first in the code, the sky loop behind it: the placement the busy path had without it)
-        s.insert(head_begin, "    if (mr_gnz != 0ull) {\n");
-        s += "    }\n    } else {                                                                 // a strip of sky\n" + loop_head + wide_block + "    }\n";
-    }          // (the closer below then ends the `else`, not the tile loop)
-    s += persist ? "    }\n    }\n}\n" : two_loops ? "    }\n    }\n}\n" : "    }\n}\n";
+    s += "    }\n}\n";
     {
         std::string tab = store_run;
         if (!E.ktab_vals.empty()) {
@@ -1192,211 +1030,6 @@ static std::string jit_source_wave(const maray_program &P, int min_waves_arg)
     return s;
 }
 
-// Source of the PIXEL kernel: one work-item per pixel, block = 256 consecutive
-// pixels of one row (a "tile"), blockIdx.y = row of this launch.  A Sin whose
-// argument is huge (|x| >= 105414350), inf or NaN does not call the slow
-// reduction here (a call site per Sin op would force every live value through
-// scratch): the tile is flagged instead and re-evaluated by the tape interpreter
-// kernel afterwards, so the final raster is identical.
-std::string jit_source(const maray_program &P, int min_waves_arg)
-{
-    validate_program(P);
-    // wave layout: 6, i.e. up to 102 SGPRs (at 8 the compiler gets 76 and spills ~400 of them to VGPR lanes, in the skeleton
-    // of bit tests and branches every pass walks; chess needs 38 VGPRs either way and runs 7 waves per SIMD)
-    if (min_waves_arg == 0) min_waves_arg = jit_px() == 4 ? 6 : 8;
-    if (jit_px() == 4) return jit_source_wave(P, min_waves_arg);
-    Emitter E(P);
-    E.ybool = jit_bool_yvals(P);
-    std::string &s = E.out;
-    s += "// generated by libmaray_hip (jit_backend.cpp) from a v" + std::to_string(P.version) + " tape: PIXEL section, " +
-         std::to_string(P.n_pix_ops) + " ops\n";
-    // y values of the block's row: scalar loads from the row table where they are used.  (MARAY_JIT_YLDS=1 stages them
-    // in LDS at block start instead -- that paid while every region's y values were live at once and spilled through
-    // v_writelane; with guards per rectangle few are, and the staging only lengthens every block's prologue: chess
-    // 70.1 -> 66.3 us per frame, 300 triangles 0.34 -> 0.28 ms without it.)
-    // tuning knobs (environment): MARAY_JIT_YLDS=0/1, MARAY_JIT_WAVES=<min waves per SIMD for __launch_bounds__>
-    const char *env_ylds = getenv("MARAY_JIT_YLDS");
-    const char *env_waves = getenv("MARAY_JIT_WAVES");
-    const int min_waves = env_waves ? atoi(env_waves) : min_waves_arg;
-    const uint32_t n_ynum = numeric_yvals(P);   // y values read as operands (a prefix of the table); the rest only gate SKIPs
-    const bool y_lds = n_ynum > 0 && n_ynum <= 4096 && env_ylds && env_ylds[0] == '1';
-    // SKIP ops whose guard is a y value (a bound of a boolean over a span of pixels): maray_jit_rows has evaluated the
-    // guards for every rectangle of `yrows` rows x 256 pixels and packed them 64 per word; the block stages the words
-    // of all its tiles in LDS, the words of the tile at hand sit in SGPRs and a region's test is one s_bitcmp1_b64.
-    // Without usable guard words (none, too many, or MARAY_JIT_ROW_GUARDS=0) those SKIP ops are compiled away.
-    const uint32_t n_gwords = jit_guard_words(P);
-    E.ignore_row_guards = n_gwords == 0;
-    const GuardPlan plan = jit_guard_plan(P);
-    if (n_gwords) { E.guard_first = n_ynum; E.guard_words = n_gwords; E.plan = &plan; }
-    if (y_lds) E.yv_name = "mr_ylds";
-    if (y_lds) s += "__shared__ double mr_ylds[" + std::to_string(n_ynum) + "];\n";
-    // MARAY_JIT_GLDS=0: the guard words of a tile by scalar loads issued one tile ahead, instead of staging the words of
-    // all the block's tiles in LDS (vector load, ds_write, barrier, ds_read + v_readfirstlane per word and tile)
-    const char *env_glds = getenv("MARAY_JIT_GLDS");
-    const bool g_lds = E.guard_words > 12 || !(env_glds && env_glds[0] == '0');
-    if (E.guard_words && g_lds) s += "__shared__ unsigned long long mr_gq[" + std::to_string((E.guard_words <= 12 ? 16 : 8) * E.guard_words) + "];     // the guard words of the block's tiles\n";
-    const bool defer = may_defer_tiles(P);
-    s += "__shared__ unsigned mr_slow_tile;\n"
-         "__device__ inline double mr_defer_sin(double) { mr_slow_tile = 1u; return 0.0; }\n"
-         "#define MR_SIN_HUGE(x) mr_defer_sin(x)   // plain Sin ops: flag the tile from the (rare) branch\n"
-         "#include \"device_math.h\"\n"
-         "typedef const __attribute__((address_space(4))) double *mr_kptr;\n/*MR_KTAB*/\n";
-    // A block owns `tiles` consecutive 256-pixel tiles of one row (blockIdx.y) and walks them in a loop, so the row's
-    // y values and guard bits are staged once per block, not once per tile.  (A program that may defer tiles is
-    // launched with tiles = 1: the work list names 256-pixel tiles.)
-    s += "extern \"C\" __global__ void __launch_bounds__(256" + (min_waves > 0 ? ", " + std::to_string(min_waves) : std::string()) +
-         ") maray_jit_pixels(unsigned char *__restrict__ rgb8, double *__restrict__ rgb64,\n"
-         "                                                                    const double *__restrict__ yvals, const MarayTex *__restrict__ tex,\n"
-         "                                                                    unsigned *__restrict__ tile_list, unsigned tile_base,\n"
-         "                                                                    const unsigned long long *__restrict__ gbits, unsigned n_tx,\n"
-         "                                                                    unsigned w, unsigned y0, unsigned n_yvals, unsigned tiles,\n"
-         "                                                                    unsigned blk_rows, unsigned blk_stride, unsigned row_base, unsigned yrows,\n"
-         "                                                                    const unsigned *__restrict__ row_order, unsigned, unsigned)\n{\n"
-         // MARAY_JIT_ROWS_REVERSED (ablation): last rows first.  For chess (board at the bottom) the dear blocks then start
-         // first and the launch's tail is sky: 71 -> 68 us per frame, i.e. the tail costs ~4 us.  Not general, not the default.
-         + std::string(getenv("MARAY_JIT_ROWS_REVERSED") ? "    const unsigned r = gridDim.y - 1u - blockIdx.y;\n" : "    const unsigned r = row_order ? row_order[blockIdx.y] : blockIdx.y;     // row of this launch (dearest groups of rows first); row_base + r = row of the whole call\n") +
-         "    const double *yrow = yvals + (size_t)r * n_yvals;\n";
-    if (defer) s += "    if (threadIdx.x == 0) mr_slow_tile = 0u;\n";
-    // every load of the prologue is issued before the first use: one memory latency, not one per round
-    const uint32_t y_rounds = y_lds ? (n_ynum + 255) / 256 : 0;
-    for (uint32_t k = 0; k < y_rounds; k++) {
-        const std::string i = std::to_string(k * 256) + "u + threadIdx.x";
-        s += "    const double ys" + std::to_string(k) + " = " + i + " < " + std::to_string(n_ynum) + "u ? yrow[" + i + "] : 0.0;\n";
-    }
-    // the guard words of all the block's tiles, fetched here with everything else: a scalar load per trip of the tile
-    // loop would put a full memory latency (the words were just written by maray_jit_guards) on every tile
-    if (E.guard_words) {
-        const std::string nw = std::to_string(E.guard_words);
-        s += "    const unsigned tile0 = blockIdx.x * tiles, my_tiles = n_tx - tile0 < tiles ? n_tx - tile0 : tiles;\n"
-             "    const unsigned long long *gsrc = gbits + ((size_t)((row_base + r) / yrows) * n_tx + tile0) * " + nw + "u;\n"
-             + (g_lds ? "    const unsigned long long gs = threadIdx.x < my_tiles * " + nw + "u ? gsrc[threadIdx.x] : 0ull;\n"
-                      : std::string("    const __attribute__((address_space(4))) unsigned long long *mr_gk = (const __attribute__((address_space(4))) unsigned long long *)gsrc;\n"));
-        if (!g_lds)
-            for (uint32_t j = 0; j < E.guard_words; j++)
-                s += "    unsigned long long nq" + std::to_string(j) + " = mr_gk[" + std::to_string(j) + "u];\n";
-    }
-    for (uint32_t k = 0; k < y_rounds; k++) {
-        const std::string i = std::to_string(k * 256) + "u + threadIdx.x";
-        s += "    if (" + i + " < " + std::to_string(n_ynum) + "u) mr_ylds[" + i + "] = ys" + std::to_string(k) + ";\n";
-    }
-    if (E.guard_words && g_lds) {
-        const std::string cap = std::to_string((E.guard_words <= 12 ? 16 : 8) * E.guard_words);
-        s += "    if (threadIdx.x < " + cap + "u) mr_gq[threadIdx.x] = gs;\n";
-        if ((E.guard_words <= 12 ? 16 : 8) * E.guard_words > 256)       // more words than threads: the rest in rounds
-            s += "    for (unsigned i = 256u + threadIdx.x; i < my_tiles * " + std::to_string(E.guard_words) + "u; i += 256u) mr_gq[i] = gsrc[i];\n";
-    }
-    if (y_lds || defer || (E.guard_words && g_lds)) s += "    __syncthreads();\n";
-    s += "    const double Y = (double)(y0 + ((row_base + r) / blk_rows) * blk_stride + (row_base + r) % blk_rows);     // -> image row (RowBlocks)\n"
-         "    unsigned long long mr_ybase = (unsigned long long)yrow;\n"
-         "    (void)Y; (void)tex; (void)gbits; (void)n_tx; (void)yrows;\n";
-    s += "    const unsigned mr_lane = threadIdx.x & 63u;                              // dword mr_lane of a wave's RGB8 run starts\n"
-         "    const unsigned mr_src = (mr_lane * 4u) / 3u, mr_shift = ((mr_lane * 4u) % 3u) * 8u;   // in pixel mr_src, mr_shift bits in\n"
-         "    for (unsigned t = 0; t < tiles; t++) {\n"
-         "    const unsigned x0 = (blockIdx.x * tiles + t) * 256u;\n"
-         "    if (x0 >= w) break;\n"
-         "    asm volatile(\"\" : \"+s\"(mr_ybase));          // y values read by scalar loads: not to be hoisted out of the loop either\n"
-         "    mr_kptr yv = (mr_kptr)mr_ybase;\n"
-         "    const __attribute__((address_space(4))) unsigned *yw = (const __attribute__((address_space(4))) unsigned *)yv;\n"
-         "    (void)yv; (void)yw;\n"
-         "/*MR_KBASE*/";
-    if (E.guard_words) {
-        if (!g_lds) {
-            for (uint32_t j = 0; j < E.guard_words; j++)
-                s += "    const mr_mask gq" + std::to_string(j) + " = nq" + std::to_string(j) + ";\n";
-            s += "    { const unsigned tn = (t + 1u < my_tiles ? t + 1u : t) * " + std::to_string(E.guard_words) + "u;\n";
-            for (uint32_t j = 0; j < E.guard_words; j++)
-                s += "      nq" + std::to_string(j) + " = mr_gk[tn + " + std::to_string(j) + "u];\n";
-            s += "    }\n";
-        } else if (E.guard_words <= 12)
-            for (uint32_t j = 0; j < E.guard_words; j++)
-                s += "    const mr_mask gq" + std::to_string(j) + " = mr_uniform64(mr_gq[t * " + std::to_string(E.guard_words) + "u + " + std::to_string(j) + "u]);\n";
-        else
-            s += "    const unsigned long long *mr_gqt = mr_gq + t * " + std::to_string(E.guard_words) + "u;        // this tile's guard words\n";
-    }
-    s += "    const unsigned x = x0 + threadIdx.x;\n"
-         "    const double X = (double)x;\n"
-         "    double o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"
-         "    float mr_defer = 0.0f;                     // fused Step(Sin) ops count their undecided cases in here\n"
-         "    (void)X; (void)mr_defer;\n";
-    if (!E.ignore_row_guards) {         // dry run: which ops yield lane masks
-        Emitter D(P);
-        D.yv_name = E.yv_name;
-        D.ignore_row_guards = true;
-        D.ybool = E.ybool;
-        D.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
-        E.bool_hint = D.is_bool_op;
-    }
-    {
-        const char *e_ = getenv("MARAY_JIT_KTAB");
-        E.ktab = !(e_ && e_[0] == '0');
-    }
-    if (E.guard_words) {
-        // Two variants of the section: one for a tile with no guard bit set (every row-guarded region is the constant 0
-        // there and the compiler folds what depends on it: for chess.maray all that is left is the background), one
-        // for the general case.  One scalar test per tile picks; most tiles of a sparse scene take the short one.
-        if (E.guard_words <= 12) {
-            std::string any = "gq0";
-            for (uint32_t j = 1; j < E.guard_words; j++) any += " | gq" + std::to_string(j);
-            s += "    if ((" + any + ") == 0ull) {\n";
-        } else {        // every wavefront looks at all the words, 64 per ballot
-            s += "    mr_mask mr_any = 0ull;\n"
-                 "    for (unsigned i0 = 0; i0 < " + std::to_string(E.guard_words) + "u; i0 += 64u) {        // the same trips on every lane: mr_any stays uniform\n"
-                 "        const unsigned i = i0 + (threadIdx.x & 63u);\n"
-                 "        mr_any |= mr_ballot((i < " + std::to_string(E.guard_words) + "u ? mr_gqt[i] : 0ull) != 0ull);\n"
-                 "    }\n"
-                 "    if (mr_any == 0ull) {\n";
-        }
-        E.assume_guards_zero = true;
-        E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
-        E.assume_guards_zero = false;
-        s += "    } else {\n";
-        E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
-        s += "    }\n";
-    } else
-        E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
-    {
-        std::string tab;
-        if (!E.ktab_vals.empty()) {
-            tab = "__constant__ double mr_kc_tab[" + std::to_string(E.ktab_vals.size()) + "] = {";
-            for (size_t j = 0; j < E.ktab_vals.size(); j++) { tab += (j % 6 ? " " : "\n    "); tab += lit(E.ktab_vals[j]); tab += ","; }
-            tab += "\n};\n";
-        }
-        s.replace(s.find("/*MR_KTAB*/"), 11, tab);
-        // The table's address, made opaque: left visible, the compiler re-derives it (s_getpc + s_add + s_addc) at every
-        // load.  Opaque anew in every trip of the tile loop, and a compiler barrier for LDS: otherwise every constant
-        // and y value is loop-invariant, gets hoisted out of the loop and lives (spills) across it.
-        s.replace(s.find("/*MR_KBASE*/"), 12, E.ktab_vals.empty() ? "    asm volatile(\"\" ::: \"memory\");\n" :
-                  "    unsigned long long mr_kbase = (unsigned long long)mr_kc_tab;\n"
-                  "    asm volatile(\"\" : \"+s\"(mr_kbase) :: \"memory\");\n"
-                  "    const mr_kptr mr_kc = (mr_kptr)mr_kbase;\n");
-    }
-    if (defer) s += "    if (mr_defer != 0.0f && x < w) mr_slow_tile = 1u;\n";
-    // RGB8: a wavefront's 64 pixels are 192 consecutive bytes.  When they are dword-aligned, lanes 0..47 each assemble
-    // one dword from the packed colours of two neighbouring lanes (two ds_bpermute) and the wave issues one coalesced
-    // store instead of three byte-strided ones.  Ragged ends and unaligned rows take the byte stores.
-    s += "    if (rgb64 && x < w) { const size_t p = ((size_t)r * w + x) * 3; rgb64[p] = o0; rgb64[p + 1] = o1; rgb64[p + 2] = o2; }\n"
-         "    if (rgb8) {\n"
-         "        const unsigned pk = mr_cast_u8(o0) | (mr_cast_u8(o1) << 8) | (mr_cast_u8(o2) << 16);\n"
-         "        const unsigned xw = x0 + (threadIdx.x & ~63u);                      // first pixel of this wavefront\n"
-         "        unsigned char *wave_out = rgb8 + ((size_t)r * w + xw) * 3;\n"
-         "        if (xw + 64u <= w && ((size_t)wave_out & 3u) == 0u) {                // wave-uniform\n"
-         "            const unsigned pa = (unsigned)__builtin_amdgcn_ds_bpermute((int)(mr_src * 4u), (int)pk);\n"
-         "            const unsigned pb = (unsigned)__builtin_amdgcn_ds_bpermute((int)(mr_src * 4u + 4u), (int)pk);\n"
-         "            const unsigned dw = (unsigned)((((unsigned long long)pb << 24) | pa) >> mr_shift);\n"
-         "            if (mr_lane < 48u) ((unsigned *)wave_out)[mr_lane] = dw;\n"
-         "        } else if (x < w) {\n"
-         "            unsigned char *q = rgb8 + ((size_t)r * w + x) * 3;\n"
-         "            q[0] = (unsigned char)pk; q[1] = (unsigned char)(pk >> 8); q[2] = (unsigned char)(pk >> 16);\n"
-         "        }\n"
-         "    }\n"
-         "    }\n";
-    if (defer)
-        s += "    __syncthreads();\n"
-             "    if (threadIdx.x == 0 && mr_slow_tile) tile_list[1u + atomicAdd(&tile_list[0], 1u)] = tile_base + r * gridDim.x + blockIdx.x;\n";
-    s += "    (void)tile_list; (void)tile_base;\n}\n";
-    return s;
-}
-
 #define RTC_TRY(expr)                                                                              \
     do {                                                                                           \
         hiprtcResult r_ = (expr);                                                                  \
@@ -1410,7 +1043,7 @@ void jit_compile(const std::string &src, std::vector<char> &code, std::string &l
     const char *headers[] = {maray_embedded_device_math_h, maray_embedded_libm_h, maray_embedded_libm_tables_h};
     const char *names[] = {"device_math.h", "maray_libm.h", "maray_libm_tables.h"};
     RTC_TRY(hiprtcCreateProgram(&prog, src.c_str(), "maray_jit.hip", 3, headers, names));
-    const char *olevel = getenv("MARAY_JIT_OPT");          // measurement knob: "-O1" builds faster
+    const char *olevel = getenv("MARAY_JIT_OPT");          // "-O1" builds faster (1.7 against 2.6 s for chess, kernel 37.4 against 35.6 us)
     std::vector<const char *> opts = {"--offload-arch=gfx950", (olevel && olevel[0] == '-') ? olevel : "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17"};
     std::vector<std::string> extra;                        // MARAY_JIT_EXTRA="-mllvm -some-flag ...": measurement knob
     if (const char *e_ = getenv("MARAY_JIT_EXTRA")) { std::istringstream in(e_); for (std::string w; in >> w;) extra.push_back(w); }
@@ -1539,7 +1172,9 @@ std::string key_salt()
     std::string rtc_id = hiprtc_path();
     struct stat st;
     if (!rtc_id.empty() && stat(rtc_id.c_str(), &st) == 0) rtc_id += ":" + std::to_string((long long)st.st_size) + ":" + std::to_string((long long)st.st_mtime);
-    return std::string(maray_version()) + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) + " " + rtc_id +
+    // the library's build id: what a launch does with the kernels (tiles per wavefront, grid shape) is library code, and a
+    // profile stamped with a code key has to mean "these kernels, launched this way"
+    return std::string(maray_version()) + "|" + maray_build_id + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) + " " + rtc_id +
            "|" + JIT_OPTIONS + "|" + (getenv("MARAY_JIT_OPT") ? getenv("MARAY_JIT_OPT") : "") + (getenv("MARAY_JIT_EXTRA") ? std::string("|") + getenv("MARAY_JIT_EXTRA") : std::string());
 }
 
@@ -1739,13 +1374,13 @@ std::shared_ptr<const JitCode> build_code(const maray_program &prog, CodeKey &k)
             have_pix = rp == HELPER_OK; have_rows = rr == HELPER_OK;
         }
     }
-    // Occupancy: the highest of 8 / 6 / 4 waves per SIMD (<= 64 / 80 / 128 VGPRs) whose build needs no scratch:
-    // spilled VGPRs are HBM traffic.  MARAY_JIT_WAVES=<n> forces a build for n waves.
-    const int ladder[] = {jit_px() == 4 ? 6 : 8, jit_px() == 4 ? 4 : 6, jit_px() == 4 ? 2 : 4};
+    // Occupancy: the highest of 6 / 4 / 2 waves per SIMD (<= 80 / 128 / 256 VGPRs) whose build needs no scratch:
+    // spilled VGPRs are HBM traffic.
+    const int ladder[] = {6, 4, 2};
     for (int i = 0; i < 3; i++) {
         if (!(i == 0 && have_pix)) jit_compile(i == 0 ? k.src_pix : jit_source(prog, ladder[i]), c->pix, log);
         c->waves = ladder[i];
-        if (code_meta_uint(c->pix, ".private_segment_fixed_size") <= 0 || getenv("MARAY_JIT_WAVES")) break;
+        if (code_meta_uint(c->pix, ".private_segment_fixed_size") <= 0) break;
     }
     if (prog.n_row_ops && !have_rows) jit_compile(k.src_rows, c->rows, log);
     c->n_row_chunks = k.n_row_chunks; c->n_gjobs = k.n_gjobs;
@@ -1822,23 +1457,15 @@ struct JitBackend final : Backend {
     unsigned *d_flags = nullptr; size_t flags_cap = 0;
     DevTex *d_tex = nullptr;
     std::vector<unsigned char *> d_tex_rgb;
-    // ROW-stage tables, twice: launch k+1's ROW kernels (on row_stream) fill one set while launch k's PIXEL kernel (on the
-    // caller's stream) still reads the other.  row_done[b]: set b is written; pix_done[b]: its reader has finished.
-    double *d_yvals2[2] = {nullptr, nullptr}; size_t yvals_cap2[2] = {0, 0};
-    unsigned long long *d_gbits2[2] = {nullptr, nullptr}; size_t gbits_cap2[2] = {0, 0};
-    hipStream_t row_stream = nullptr;
-    hipEvent_t row_done[2] = {nullptr, nullptr}, pix_done[2] = {nullptr, nullptr};
-    bool row_done_set[2] = {false, false}, pix_done_set[2] = {false, false};
-    int cur_set = 0;
+    double *d_yvals = nullptr; size_t yvals_cap = 0;          // ROW-stage tables (the context's, not a launch's: launches are ordered by their stream)
+    unsigned long long *d_gbits = nullptr; size_t gbits_cap = 0;
     unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;      // time_rows without a caller's buffer
     HostPipe pipe;                      // streams + staging of the host-raster entry points
     hipStream_t own_stream = nullptr;   // = pipe's compute stream
     uint32_t n_row_chunks = 1, n_gwords = 0, n_gjobs = 0, guard_rows = 1, guard_sub = 1;       // guard_sub: guard rectangles per 256-pixel tile
     uint32_t n_cu = 256;
-    // launch-time tuning knobs, read once when the context is created
-    bool k_overlap = false, k_coop = false, k_persist = false, wide_all = false, k_swz = false;
-    unsigned k_row_block = 256, k_tiles = 0, k_per_cu = 7;
-    uint32_t px = 4;                    // pixels per lane of the PIXEL kernel this context was built with
+    bool wide_all = false;              // the whole section runs four pixels per lane (jit_wide_general)
+    unsigned k_tiles = 0;               // MARAY_JIT_TILES: tiles per wavefront (0 = by launch size), read once when the context is created
     bool has_sin = false;               // some Sin argument is not proven bounded: tiles may be deferred to `slow`
     hipStream_t last_stream = nullptr; bool have_last = false;      // the stream of the last launch (see launch())
     hipEvent_t handover = nullptr;
@@ -1852,12 +1479,7 @@ struct JitBackend final : Backend {
         (void)hipFree(d_tex);
         for (auto p : d_tex_rgb) (void)hipFree(p);
         (void)hipFree(d_order); (void)hipFree(d_rgb8);
-        for (int b = 0; b < 2; b++) {
-            (void)hipFree(d_yvals2[b]); (void)hipFree(d_gbits2[b]);
-            if (row_done[b]) (void)hipEventDestroy(row_done[b]);
-            if (pix_done[b]) (void)hipEventDestroy(pix_done[b]);
-        }
-        if (row_stream) (void)hipStreamDestroy(row_stream);
+        (void)hipFree(d_yvals); (void)hipFree(d_gbits);
         if (handover) (void)hipEventDestroy(handover);
     }
 
@@ -1879,18 +1501,8 @@ struct JitBackend final : Backend {
             throw Error{MARAY_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only"};
         n_cu = (uint32_t)std::max(1, prop.multiProcessorCount);
         has_sin = may_defer_tiles(prog);
-        px = jit_px();
-        k_coop = jit_coop(); k_persist = jit_persist();
         wide_all = jit_wide_general(prog);
-        if (const char *e_ = getenv("MARAY_JIT_ROW_OVERLAP")) k_overlap = e_[0] == '1';
-        // MARAY_JIT_SWIZZLE=1: a row's blocks take its strips rotated by the row (the kernel's `swz`), so that a column of the
-        // image meets every XCD.  Measured both ways: chess @16384^2 with 8 blocks per row 530 -> 517 us per frame, with 4
-        // blocks per row (what such a launch takes now) 474 -> 498; 2 blocks per row, symmetric or lopsided scene: nothing.
-        // Off by default.
-        if (const char *e_ = getenv("MARAY_JIT_SWIZZLE")) k_swz = e_[0] == '1';
-        k_row_block = jit_row_block();
         if (const char *e_ = getenv("MARAY_JIT_TILES")) if (atoi(e_) > 0) k_tiles = (unsigned)atoi(e_);
-        if (const char *e_ = getenv("MARAY_JIT_BLOCKS_PER_CU")) if (atoi(e_) > 0) k_per_cu = (unsigned)atoi(e_);
         lap("device");
         code = jit_code_for(prog);                       // built by the first context of the process, or read from the cache
         lap("code objects");
@@ -1905,7 +1517,7 @@ struct JitBackend final : Backend {
             HIP_TRY(hipModuleLoadData(&mod_rows, code->rows.data()));
             HIP_TRY(hipModuleGetFunction(&f_rows, mod_rows, "maray_jit_rows"));
             n_gwords = jit_guard_words(prog);
-            if (n_gwords && !(getenv("MARAY_JIT_NO_ORDER") && getenv("MARAY_JIT_NO_ORDER")[0] == '1')) HIP_TRY(hipModuleGetFunction(&f_order, mod_rows, "maray_jit_order"));
+            if (n_gwords) HIP_TRY(hipModuleGetFunction(&f_order, mod_rows, "maray_jit_order"));
             guard_rows = jit_guard_rows(prog);
             guard_sub = 256u / jit_guard_geom(prog).gw;
             lap("load ROW module");
@@ -1915,13 +1527,6 @@ struct JitBackend final : Backend {
         lap("host pipe");
         own_stream = pipe.compute_stream();
         HIP_TRY(hipEventCreateWithFlags(&handover, hipEventDisableTiming));
-        if (k_overlap) {                                  // (a stream costs a context several milliseconds: only when it is used)
-            HIP_TRY(hipStreamCreateWithFlags(&row_stream, hipStreamNonBlocking));
-            for (int b = 0; b < 2; b++) {
-                HIP_TRY(hipEventCreateWithFlags(&row_done[b], hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&pix_done[b], hipEventDisableTiming));
-            }
-        }
         std::vector<DevTex> descs(n_tex ? n_tex : 1);
         for (uint32_t i = 0; i < n_tex; i++) {
             unsigned char *d = nullptr;
@@ -1960,25 +1565,15 @@ struct JitBackend final : Backend {
         // rows per guard evaluation: a group must not straddle two row blocks (its image rows have to be consecutive)
         unsigned yrows = (guard_rows > 1 && (blk_rows >= rows_total || blk_rows % guard_rows == 0)) ? guard_rows : 1u;
         const uint32_t n_groups = (rows_total + yrows - 1) / yrows;
-        // MARAY_JIT_ROW_OVERLAP=1: the ROW stage (y values, guard bits: ~10 us of latency-bound work on few wavefronts) runs
-        // on a stream of its own into the table set the previous launch is not reading, so that it overlaps that launch's
-        // PIXEL kernel; this launch's PIXEL kernel waits for it by event.  Not the default: the two kernels then share the
-        // SIMDs, the PIXEL kernel slows down by what the ROW kernel saves (chess: 58.5 against 57.1 us per frame).
-        const bool overlap = k_overlap;
-        const int b = rows_pass ? (cur_set ^ 1) : cur_set;
-        hipStream_t rs = overlap ? row_stream : st;
+        // (the ROW stage on a stream of its own under the previous launch's PIXEL kernel was measured and lost: the two kernels
+        // share the SIMDs and the events that order the streams cost a signal round trip each)
         if (rows_pass) {
-            // (one stream: launches are ordered already, and an event wait between them costs a signal round trip: 5.7 us per frame)
-            if (overlap && pix_done_set[b]) HIP_TRY(hipStreamWaitEvent(rs, pix_done[b], 0));       // the reader of this set has finished
-            ensure(d_yvals2[b], yvals_cap2[b], (size_t)rows_total * std::max<uint32_t>(P.n_yvals, 1));
-            const size_t had = gbits_cap2[b];
-            ensure(d_gbits2[b], gbits_cap2[b], (size_t)n_groups * ((w + 255) / 256) * guard_sub * std::max<uint32_t>(n_gwords, 1));
+            ensure(d_yvals, yvals_cap, (size_t)rows_total * std::max<uint32_t>(P.n_yvals, 1));
+            const size_t had = gbits_cap;
+            ensure(d_gbits, gbits_cap, (size_t)n_groups * ((w + 255) / 256) * guard_sub * std::max<uint32_t>(n_gwords, 1));
             // bits past the last guard belong to no job and are never written: zero them once (the pixel kernel tests whole words)
-            if (gbits_cap2[b] != had) HIP_TRY(hipMemsetAsync(d_gbits2[b], 0, gbits_cap2[b] * sizeof(unsigned long long), rs));
-            cur_set = b;
+            if (gbits_cap != had) HIP_TRY(hipMemsetAsync(d_gbits, 0, gbits_cap * sizeof(unsigned long long), st));
         }
-        double *d_yvals = d_yvals2[b];
-        unsigned long long *d_gbits = d_gbits2[b];
         if (!d_yvals || !d_gbits) throw Error{MARAY_E_INTERNAL, "launch without a ROW pass before any ROW pass"};
         unsigned n_yvals = P.n_yvals;
         if (rows_pass && P.n_row_ops) {
@@ -1986,11 +1581,11 @@ struct JitBackend final : Backend {
             unsigned n_tx_ = (w + 255) / 256 * guard_sub;
             // guards: one item per rectangle (group of yrows rows, run of 256 / guard_sub pixels); y values: one per row
             const uint64_t items = std::max<uint64_t>(n_gwords ? (uint64_t)n_groups * n_tx_ : 0, rows_total);
-            const unsigned bs = k_row_block;
+            const unsigned bs = ROW_BLOCK;
             if (items + bs > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
             void *args[] = {&d_yvals, &d_gbits, &d_tex, &yy0, &rr, &n_yvals, &ww, &n_tx_, &blk_rows, &blk_stride, &yrows};
             unsigned gy = n_row_chunks + n_gjobs;
-            HIP_TRY(hipModuleLaunchKernel(f_rows, (unsigned)((items + bs - 1) / bs), gy, 1, bs, 1, 1, 0, rs, args, nullptr));
+            HIP_TRY(hipModuleLaunchKernel(f_rows, (unsigned)((items + bs - 1) / bs), gy, 1, bs, 1, 1, 0, st, args, nullptr));
         }
         // launch order of the PIXEL kernel (maray_jit_order): once per geometry, from the guard bits the ROW kernel just wrote;
         // a cached order is used by every launch of that geometry, with or without a ROW pass (time_rows)
@@ -2005,90 +1600,49 @@ struct JitBackend final : Backend {
             seen_key[0] = key[0]; seen_key[1] = key[1]; seen_key[2] = key[2];
             if (!cached && rows_pass && again) {
                 order_key[0] = order_key[1] = order_key[2] = 0;     // no geometry owns d_order until the kernel below is enqueued
-                // an earlier launch (another geometry) may still be reading the table: its pixel kernel first
-                if (overlap && pix_done_set[b ^ 1]) HIP_TRY(hipStreamWaitEvent(rs, pix_done[b ^ 1], 0));
                 ensure(d_order, order_cap, (size_t)rows_total);
                 unsigned rr = rows_total, n_tx_ = (w + 255) / 256 * guard_sub;
                 void *oargs[] = {&d_gbits, &d_order, &rr, &n_tx_, &yrows};
-                HIP_TRY(hipModuleLaunchKernel(f_order, 1, 1, 1, 256, 1, 1, n_groups * 4, rs, oargs, nullptr));
+                HIP_TRY(hipModuleLaunchKernel(f_order, 1, 1, 1, 256, 1, 1, n_groups * 4, st, oargs, nullptr));
                 order_key[0] = key[0]; order_key[1] = key[1]; order_key[2] = key[2];
             }
             if (key[0] == order_key[0] && key[1] == order_key[1] && key[2] == order_key[2]) row_order = d_order;
         }
-        if (rows_pass && rs != st) {
-            HIP_TRY(hipEventRecord(row_done[b], rs));
-            row_done_set[b] = true;
-        }
-        if (row_done_set[b] && rs != st) HIP_TRY(hipStreamWaitEvent(st, row_done[b], 0));
         const unsigned n_tx = (w + 255) / 256;
         const uint64_t n_tiles = (uint64_t)n_tx * rows_total;
-        // tiles per block: amortise the per-block prologue, but rows cost what they show (sky: nothing, board: 5x the
-        // average) and blocks are the unit of load balance (chess @4096^2, tiles = 2 / 4 / 8 / 16: 68 / 59 / 52 / 58 us;
-        // walking the rows in a scattered order to mix cheap and dear ones costs more in cache locality than it balances)
-        unsigned tiles, gx;
-        if (px == 4) {
-            // a block (or, MARAY_JIT_LAYOUT=wave, a wavefront) owns `tiles` consecutive tiles of a row; a strip's guard
-            // words are one word per lane of a wavefront
-            // (every tile of a program without guards costs the same: long strips, nothing to balance -- config 2 at 8192^2:
-            // 2.74 -> 2.88 TB/s with 8 tiles; only for the cheap four-wide sections, a narrow wavefront would live too long)
-            const bool coop = k_coop;
-            // (a launch that fills the device only a few times over -- chess up to 2048^2 -- is a matter of how long its longest
-            // wavefront lives, not of throughput: one tile per wavefront then; 1024^2 / 2048^2 / 4096^2 / 8192^2 with 1 tile:
-            // 20.3 / 18.9 / 48.4 / 149 us per step, with 2: 25.5 / 24.8 / 42.3 / 138)
-            // ... and a launch that fills it dozens of times over is a matter of what every wavefront costs before its first
-            // pixel, its tail is short against the whole: four tiles per wavefront (8192^2 / 16384^2 with 2 / 3 / 4 / 5 tiles:
-            // 138 / 123 / 119 / 139 and 517 / 487 / 497 / 566 us per step; 4096^2: 42.2 / 55.5 / 44.6 / 46.9)
-            const uint64_t device_slots = (uint64_t)n_cu * 4 * 7;
-            tiles = coop || wide_all ? 8 : (n_tiles <= 4 * device_slots ? 1 : n_tiles <= 16 * device_slots ? 2 : 4);
-            if (k_tiles) tiles = std::min(64u, k_tiles);
-            if (n_gwords && n_gwords <= jit_gw_inline_max()) tiles = std::min(tiles, 64u / (n_gwords * guard_sub));
-            tiles = std::max(1u, std::min(tiles, n_tx));
-            gx = coop ? (n_tx + tiles - 1) / tiles : (n_tx + 4 * tiles - 1) / (4 * tiles);
-            if (const char *e_ = getenv("MARAY_JIT_PAD_GRID")) if (atoi(e_) > 1) gx *= (unsigned)atoi(e_);      // measurement: blocks that exit at once
-        } else {
-            tiles = has_sin ? 1u : (unsigned)std::min<uint64_t>(std::min<uint64_t>(8, n_tx), std::max<uint64_t>(1, n_tiles / 4096));
-            if (k_tiles && !has_sin) tiles = std::min(n_gwords > 12 ? 8u : 16u, k_tiles);      // (the kernel stages guard words for <= 16 / 8 tiles)
-            gx = (n_tx + tiles - 1) / tiles;
-        }
+        // Tiles per wavefront.  Every tile of a program without guards costs the same: long strips, nothing to balance (config 2
+        // at 8192^2: 2.74 -> 2.88 TB/s with 8 tiles; only for the cheap four-wide sections, a narrow wavefront would live too
+        // long).  Else rows cost what they show (sky: nothing, board: 5x the average) and wavefronts are the unit of load
+        // balance: a launch that fills the device only a few times over -- chess up to 2048^2 -- is a matter of how long its
+        // longest wavefront lives, not of throughput: one tile per wavefront (1024^2 / 2048^2 / 4096^2 / 8192^2 with 1 tile:
+        // 20.3 / 18.9 / 48.4 / 149 us per step, with 2: 25.5 / 24.8 / 42.3 / 138); a launch that fills it dozens of times over
+        // is a matter of what every wavefront costs before its first pixel, its tail is short against the whole: four tiles
+        // (8192^2 / 16384^2 with 2 / 3 / 4 / 5 tiles: 138 / 123 / 119 / 139 and 517 / 487 / 497 / 566 us per step; 4096^2:
+        // 42.2 / 55.5 / 44.6 / 46.9)
+        const uint64_t device_slots = (uint64_t)n_cu * 4 * 7;
+        unsigned tiles = wide_all ? 8 : (n_tiles <= 4 * device_slots ? 1 : n_tiles <= 16 * device_slots ? 2 : 4);
+        if (k_tiles) tiles = std::min(64u, k_tiles);
+        if (n_gwords && n_gwords <= GW_INLINE_MAX) tiles = std::min(tiles, 64u / (n_gwords * guard_sub));      // a strip's guard words: one per lane
+        tiles = std::max(1u, std::min(tiles, n_tx));
+        const unsigned gx = (n_tx + 4 * tiles - 1) / (4 * tiles);
         if (n_tiles > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
-        ensure(d_flags, flags_cap, (size_t)n_tiles * 4 + 1);                // work list {count, tile, ...} of deferred tiles (each of a tile's four wavefronts may name it)
-        if (has_sin) HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(unsigned), st));
-        if (px == 4 && k_persist) {
-            // persistent wavefronts: one launch whatever the number of rows, the grid sized to fill the device once
-            const unsigned strips = (n_tx + tiles - 1) / tiles;
-            const uint64_t items = (uint64_t)strips * rows_total;
-            if (items > 0xFFFFFFFFull) throw Error{MARAY_E_ARG, "too many tiles in one launch; render fewer rows per call"};
-            const unsigned per_cu = k_per_cu;
-            const unsigned blocks = (unsigned)std::min<uint64_t>((items + 3) / 4, (uint64_t)n_cu * per_cu);
-            unsigned shift = 0xFFFFFFFFu;
-            for (unsigned k = 0; k < 31; k++) if (strips == (1u << k)) shift = k;
-            unsigned ww = w, yy0 = y0, tile_base = 0, row_base = 0, rr = rows_total, ntx = n_tx;
-            const unsigned long long *gb = d_gbits;
-            unsigned *fl = d_flags;
-            const double *yv = d_yvals;
-            unsigned swz = 0;
-            void *args[] = {&d8, &d64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles, &blk_rows, &blk_stride, &row_base, &yrows, &row_order, &rr, &shift, &swz};
-            HIP_TRY(hipModuleLaunchKernel(f_pix, blocks, 1, 1, 256, 1, 1, 0, st, args, nullptr));
-        } else
+        if (has_sin) {
+            ensure(d_flags, flags_cap, (size_t)n_tiles + 1);                // work list {count, tile, ...} of deferred tiles
+            HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(unsigned), st));
+        }
         for (uint32_t r0 = 0; r0 < rows_total; r0 += 65535) {          // gridDim.y limit
             const uint32_t rows = std::min<uint32_t>(65535, rows_total - r0);
             unsigned char *p8 = d8 ? d8 + (size_t)r0 * w * 3 : nullptr;
             double *p64 = d64 ? d64 + (size_t)r0 * w * 3 : nullptr;
             const double *yv = d_yvals + (size_t)r0 * n_yvals;
             unsigned *fl = d_flags;
-            unsigned ww = w, yy0 = y0, tile_base = r0 * (px == 4 ? n_tx : gx), row_base = r0, rr = rows, shift = 0xFFFFFFFFu;
+            unsigned ww = w, yy0 = y0, tile_base = r0 * n_tx, row_base = r0;
             const unsigned long long *gb = d_gbits;              // indexed by the row of the whole call
             unsigned ntx = n_tx;
-            // (the kernels of the other layouts take no `swz`: a trailing element of `args` they do not declare is not read)
-            unsigned swz = (px == 4 && !k_coop && k_swz && gx > 1 && (gx & (gx - 1)) == 0) ? gx - 1 : 0u;
-            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles, &blk_rows, &blk_stride, &row_base, &yrows, &row_order, &rr, &shift, &swz};
+            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles, &blk_rows, &blk_stride, &row_base, &yrows, &row_order};
             HIP_TRY(hipModuleLaunchKernel(f_pix, gx, rows, 1, 256, 1, 1, 0, st, args, nullptr));
         }
         if (has_sin) slow->render_flagged(w, rb, d8, d64, st, d_flags, d_yvals);   // no-op unless a tile was deferred
-        if (overlap) {
-            HIP_TRY(hipEventRecord(pix_done[b], st));
-            pix_done_set[b] = true;
-        }
     }
 
     void render_device(uint32_t w, uint32_t, const RowBlocks &rb, void *d8, void *d64, void *stream) override {

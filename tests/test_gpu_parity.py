@@ -494,25 +494,16 @@ def test_guards_per_group_of_rows_with_ragged_ranges(chess_bytes):
 
 
 def test_specialised_kernel_variants_selected_by_tuning_knobs(chess_bytes, monkeypatch):
-    """Paths the default build of chess does not take.  Of the default layout (a wavefront per 256-pixel tile): the block's
-    four wavefronts side by side on a busy tile, guard words by scalar loads, the whole section four pixels per lane, y
-    values all numeric, no private ROW stream, other strip lengths, other guard rectangles (256 x 8 was round 1's), a
-    pass-level sky variant, two pixels per lane on busy tiles.  And the first layout (one pixel per lane throughout,
-    MARAY_JIT_PX=1) with its own knobs: y values staged in LDS, guards compiled away, one tile per block, literal constants."""
+    """The eight knobs the specialised path still has, each on a path the default build of chess does
+    not take: other strip lengths, other guard rectangles (256 x 8 was round 1's: the tile's words are then taken per
+    tile, not per pass), every wave-level region kept or none, guards compiled away, an in-process build at -O1.  The
+    layouts that lost (r2_ablations.jsonl) are gone from the library, and their knobs with them."""
     g = json.load(open(os.path.join(GOLDEN, 'chess_1024.json')))
     tape = M.Scene(chess_bytes).lower()
-    px1 = {'MARAY_JIT_PX': '1'}
-    for env in ({'MARAY_JIT_LAYOUT': 'coop'}, {'MARAY_JIT_LAYOUT': 'coop', 'MARAY_JIT_TILES': '3'}, {'MARAY_JIT_GW': 'sload'}, {'MARAY_JIT_WIDE': '1'},
-                {'MARAY_JIT_YBOOL': '0'}, {'MARAY_JIT_ROW_OVERLAP': '1'}, {'MARAY_JIT_DERIVED': '0'}, {'MARAY_JIT_TILES': '1'}, {'MARAY_JIT_TILES': '5', 'MARAY_JIT_ROW_BLOCK': '64'},
-                {'MARAY_JIT_ROW_GUARDS': '0'}, {'MARAY_JIT_KTAB': '0'}, {'MARAY_JIT_NO_ORDER': '1'}, {'MARAY_JIT_ROW_CHUNK_OPS': '300'},
-                {'MARAY_JIT_PERSIST': '1'}, {'MARAY_JIT_PERSIST': '1', 'MARAY_JIT_TILES': '3', 'MARAY_JIT_BLOCKS_PER_CU': '2'},
-                {'MARAY_JIT_GW_MANY': '1'}, {'MARAY_JIT_GW_MANY': '1', 'MARAY_JIT_TILES': '5'},
-                {'MARAY_JIT_GUARD_W': '256', 'MARAY_JIT_GUARD_H': '8'}, {'MARAY_JIT_GUARD_W': '128', 'MARAY_JIT_GUARD_H': '16', 'MARAY_JIT_TILES': '3'},
-                {'MARAY_JIT_GUARD_W': '64', 'MARAY_JIT_GUARD_H': '128'}, {'MARAY_JIT_PASS_SKY': '1'}, {'MARAY_JIT_GUARD_W': '256', 'MARAY_JIT_NARROW': '2'},
-                {'MARAY_JIT_TILES': '7'}, {'MARAY_JIT_SWIZZLE': '1'}, {'MARAY_JIT_SWIZZLE': '1', 'MARAY_JIT_TILES': '1'}, {'MARAY_JIT_EXPECT': '0'}, {'MARAY_JIT_TWO_LOOPS': '1'}, {'MARAY_JIT_TWO_LOOPS': '1', 'MARAY_JIT_TILES': '5'}, {'MARAY_JIT_TWO_LOOPS': '2'}, {'MARAY_JIT_TWO_LOOPS': '2', 'MARAY_JIT_TILES': '3'}, {'MARAY_JIT_ROW_MIN_REGION': '0'}, {'MARAY_JIT_ROW_MIN_REGION': '100000'},
-                {'MARAY_JIT_PAD_GRID': '3'}, {'MARAY_JIT_TILES': '1', 'MARAY_JIT_PAD_GRID': '2'},
-                px1, dict(px1, MARAY_JIT_YLDS='1'), dict(px1, MARAY_JIT_ROW_GUARDS='0'), dict(px1, MARAY_JIT_TILES='1'), dict(px1, MARAY_JIT_KTAB='0'),
-                dict(px1, MARAY_JIT_ROW_BLOCK='64', MARAY_JIT_TILES='3'), dict(px1, MARAY_JIT_GLDS='0'), dict(px1, MARAY_JIT_ROWS_REVERSED='1')):
+    for env in ({'MARAY_JIT_TILES': '1'}, {'MARAY_JIT_TILES': '5'}, {'MARAY_JIT_GUARD_W': '256', 'MARAY_JIT_GUARD_H': '8'},
+                {'MARAY_JIT_GUARD_W': '128', 'MARAY_JIT_GUARD_H': '16', 'MARAY_JIT_TILES': '3'}, {'MARAY_JIT_GUARD_W': '64', 'MARAY_JIT_GUARD_H': '128'},
+                {'MARAY_JIT_MIN_REGION': '0'}, {'MARAY_JIT_MIN_REGION': '100000'}, {'MARAY_JIT_ROW_GUARDS': '0'},
+                {'MARAY_JIT_HELPER': '0', 'MARAY_JIT_OPT': '-O1'}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         ctx = M.Context(tape, backend=M.BACKEND_JIT)
