@@ -27,7 +27,8 @@
 namespace maray_build {
 
 enum Tag : uint32_t {
-    Arc = 0, X, Y, Tau, E, Var, Nat, Neg, Abs, Recip, Sqrt, Step, Sin, Exp, Ln, Add, Mul, Max, Min, Let, Decor, App
+    Arc = 0, X, Y, Tau, E, Var, Nat, Neg, Abs, Recip, Sqrt, Step, Sin, Exp, Ln, Add, Mul, Max, Min, Let, Decor, App,
+    Encoded = 0xFFFFFFFFu       // not a variant of the reference's Expr: an expression already in its bincode form (see encoded())
 };
 
 struct Node;
@@ -41,6 +42,7 @@ struct Node {
     uint64_t u = 0;                                 // Var id / Nat value / App id
     Expr a, b;
     std::vector<std::pair<uint64_t, Expr>> vars;    // Let
+    std::vector<uint8_t> raw;                       // Encoded
 };
 
 inline Expr mk(Tag t, Expr a = nullptr, Expr b = nullptr, uint64_t u = 0)
@@ -76,6 +78,15 @@ inline Expr let_(std::vector<std::pair<uint64_t, Expr>> vars, Expr body)
 {
     auto n = std::make_shared<Node>();
     n->tag = Let; n->vars = std::move(vars); n->a = std::move(body);
+    return n;
+}
+// An expression that exists as bytes: what `Expr::simplify(mem).compress(mem)` returns when the two passes are done by
+// libmaray_hip (maray_scene_simplify_ex / maray_scene_compress work on encoded scenes).  `save` writes the bytes as they
+// are, so `mul(encoded(shape_bytes), nat(255))` is examples/chess.rs:43-45.  Opaque to subst2 / scale / translate.
+inline Expr encoded(std::vector<uint8_t> bincode_of_one_expr)
+{
+    auto n = std::make_shared<Node>();
+    n->tag = Encoded; n->raw = std::move(bincode_of_one_expr);
     return n;
 }
 inline Expr pi() { return div(tau(), nat(2)); }
@@ -209,7 +220,7 @@ inline Expr subst2(const Expr &ex, const Point2 &p)
     case Arc: return subst2(ex->a, p);
     case X: return p[0];
     case Y: return p[1];
-    case Tau: case E: case Var: case Nat: case Let: return ex;
+    case Tau: case E: case Var: case Nat: case Let: case Encoded: return ex;
     case App: return app((uint32_t)ex->u, subst2(ex->a, p), subst2(ex->b, p));
     default: return mk(ex->tag, subst2(ex->a, p), ex->b ? subst2(ex->b, p) : nullptr, ex->u);
     }
@@ -222,6 +233,7 @@ inline void encode_expr(const Expr &ex, std::vector<uint8_t> &out)
 {
     auto u32 = [&](uint32_t v) { uint8_t b[4]; memcpy(b, &v, 4); out.insert(out.end(), b, b + 4); };
     auto u64 = [&](uint64_t v) { uint8_t b[8]; memcpy(b, &v, 8); out.insert(out.end(), b, b + 8); };
+    if (ex->tag == Encoded) { out.insert(out.end(), ex->raw.begin(), ex->raw.end()); return; }
     u32(ex->tag);
     switch (ex->tag) {
     case X: case Y: case Tau: case E: break;

@@ -76,6 +76,14 @@ int maray_scene_rescale(maray_scene *s, uint32_t sx, uint32_t sy);
  * then the rewrite rules of src/simplify.rs:129-327).  Authoring-time, not on the render path; the reference applies it
  * before `save` (examples/chess.rs:43). */
 int maray_scene_simplify(maray_scene *s);
+/* The same with options.  MARAY_SIMPLIFY_MERGE_DIVISORS: one rewrite the reference does not have, `(a/p) * 1/q -> a / (p*q)`.
+ * The reference's rules do not terminate on such a term -- src/simplify.rs:276-283 turns `(a/p) * 1/q` into `(a * 1/q) / p`,
+ * whose numerator is the quotient a/q again, and the two divisors change places for ever (the reference overflows its
+ * stack; maray_scene_simplify reports MARAY_E_LIMIT) -- and examples/chess.rs:43 builds such terms from every grid cell,
+ * so the current revision cannot regenerate its own data/chess.maray (written by an older one: legacy tags, and naturals
+ * that are products of such divisors).  With the flag the example's pipeline runs. */
+enum { MARAY_SIMPLIFY_MERGE_DIVISORS = 1 };
+int maray_scene_simplify_ex(maray_scene *s, uint32_t flags);
 /* `Expr::compress` on each channel (src/lib.rs:610-614: `flatten`, src/compressor.rs:167-211, then the greedy
  * Let-introducing loop of `compress`, :214-236, driven by the printed length of every candidate term exactly as the
  * reference's `Display` prints it).  Changes no value.  n_vars3 (may be NULL): variables introduced per channel. */
@@ -248,6 +256,10 @@ typedef struct maray_gen_opts {
 int maray_gen_to_image(const maray_scene *s, const maray_texture *tex, uint32_t n_tex,
                        const maray_gen_opts *opts, maray_report report, maray_report_fn fn, void *user,
                        uint8_t *rgb8, uint32_t w, uint32_t h);
+/* gen_to_image keeps what a call sets up -- the scene's tape and one context per device -- for the next call with the
+ * same scene, textures and back-end (the last MARAY_GEN_CACHE programs, default 4, 0 = none): an animation that calls
+ * it in a loop (examples/test*.rs) pays the lowering and the context creation once, not per frame.  This frees them. */
+void maray_gen_cache_clear(void);
 /* gen: render and write a PNG (progress callback prints "%.2f %%" to stderr
  * and re-saves the partial image, like src/lib.rs:1203-1208). */
 int maray_gen(const maray_scene *s, const maray_texture *tex, uint32_t n_tex,

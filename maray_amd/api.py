@@ -91,6 +91,7 @@ def lib():
         'maray_scene_fix_color': (C.c_int, [vp]),
         'maray_scene_rescale': (C.c_int, [vp, u32, u32]),
         'maray_scene_simplify': (C.c_int, [vp]),
+        'maray_scene_simplify_ex': (C.c_int, [vp, C.c_uint32]),
         'maray_scene_compress': (C.c_int, [vp, C.POINTER(u32)]),
         'maray_scene_display_len': (C.c_int, [vp, C.c_int, u64p]),
         'maray_lower': (C.c_int, [vp, C.POINTER(LowerOpts), C.POINTER(vp)]),
@@ -117,6 +118,7 @@ def lib():
         'maray_gen_to_image': (C.c_int, [vp, C.POINTER(Texture), u32, C.POINTER(GenOpts), Report, REPORT_FN, vp, vp,
                                          u32, u32]),
         'maray_gen': (C.c_int, [vp, C.POINTER(Texture), u32, C.POINTER(GenOpts), Report, C.c_char_p]),
+        'maray_gen_cache_clear': (None, []),
         'maray_png_write': (C.c_int, [C.c_char_p, vp, u32, u32]),
         'maray_png_read': (C.c_int, [C.c_char_p, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]),
         'maray_free': (None, [vp]),
@@ -211,9 +213,13 @@ class Scene:
     def fix_color(self):
         _check(lib().maray_scene_fix_color(self._h))
 
-    def simplify(self):
-        """Expr::simplify on each channel (authoring-time rewrite rules of the reference)."""
-        _check(lib().maray_scene_simplify(self._h))
+    def simplify(self, merge_divisors=False):
+        """Expr::simplify on each channel (authoring-time rewrite rules of the reference).  merge_divisors: the one rewrite
+        the reference lacks, without which its rules do not terminate on examples/chess.rs (maray_hip.h)."""
+        if merge_divisors:
+            _check(lib().maray_scene_simplify_ex(self._h, 1))
+        else:
+            _check(lib().maray_scene_simplify(self._h))
 
     def compress(self):
         """Expr::compress on each channel (authoring-time: names repeated sub-expressions); returns the variables introduced."""
@@ -397,6 +403,11 @@ def gen(scene, path, textures=None, backend=BACKEND_AUTO, n_devices=0, report_ki
     go = GenOpts()
     go.backend, go.n_devices = backend, n_devices
     _check(lib().maray_gen(scene._h, arr, n, C.byref(go), Report(report_kind, report_value), os.fsencode(path)))
+
+
+def gen_cache_clear():
+    """Frees the tapes and contexts maray_gen_to_image keeps between calls."""
+    lib().maray_gen_cache_clear()
 
 
 def png_write(path, rgb8):

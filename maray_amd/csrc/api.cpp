@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -18,7 +19,14 @@
 
 using namespace maray;
 
-struct maray_scene { Scene s; };
+struct maray_scene {
+    Scene s;
+    // 128-bit hash of the scene's encoding (what `save` would write): the name maray_gen_to_image remembers a scene's
+    // tape and contexts under.  Computed on first use, dropped by every call that changes the scene.
+    std::mutex key_mutex;
+    bool key_valid = false;
+    uint64_t key[2] = {0, 0};
+};
 struct maray_tape { Tape t; };
 
 namespace {
@@ -79,6 +87,41 @@ int guard(F f)
 namespace maray {
 
 void set_last_error(const std::string &m) { g_err = m; }
+
+// Two 64-bit lanes, eight bytes a step (a cache key, not a defence: ~4 GB/s, so that a render call can afford to hash
+// its textures)
+void hash128(const void *data, size_t n, uint64_t h[2])
+{
+    const unsigned char *p = (const unsigned char *)data;
+    uint64_t a = h[0] ^ (n * 0x9e3779b97f4a7c15ull), b = h[1] + n;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        a = (a ^ w) * 0xff51afd7ed558ccdull; a = (a << 29) | (a >> 35);
+        b = (b + w) * 0xc4ceb9fe1a85ec53ull; b ^= b >> 31;
+    }
+    uint64_t w = 0;
+    memcpy(&w, p + i, n - i);
+    a = (a ^ w) * 0xff51afd7ed558ccdull; a ^= a >> 33;
+    b = (b + w) * 0xc4ceb9fe1a85ec53ull; b ^= b >> 29;
+    h[0] = a * 0x9e3779b97f4a7c15ull; h[1] = b ^ a;
+}
+
+void scene_cache_key(const maray_scene *cs, uint64_t out[2])
+{
+    maray_scene *s = const_cast<maray_scene *>(cs);              // (the key is a cache inside the handle)
+    std::lock_guard<std::mutex> lk(s->key_mutex);
+    if (!s->key_valid) {
+        std::vector<uint8_t> b;
+        run_big_stack([&] { scene_encode(s->s, b); });
+        // (the header's size is not part of a scene's program: maray_gen_to_image takes the size as arguments)
+        s->key[0] = 0x6d61726179ull; s->key[1] = 3;
+        hash128(b.data() + 8, b.size() >= 8 ? b.size() - 8 : 0, s->key);
+        s->key_valid = true;
+    }
+    out[0] = s->key[0]; out[1] = s->key[1];
+}
 
 void validate_program(const maray_program &p)
 {
@@ -202,7 +245,7 @@ int maray_scene_size(const maray_scene *s, uint32_t *w, uint32_t *h)
 
 int maray_scene_set_size(maray_scene *s, uint32_t w, uint32_t h)
 {
-    return guard([&] { REQUIRE(s, "null argument"); s->s.w = w; s->s.h = h; });
+    return guard([&] { REQUIRE(s, "null argument"); s->key_valid = false; s->s.w = w; s->s.h = h; });
 }
 
 int maray_scene_is_legacy(const maray_scene *s, int *legacy)
@@ -245,28 +288,37 @@ int maray_scene_save(const maray_scene *s, const char *path)
 
 int maray_scene_fix_color(maray_scene *s)
 {
-    return guard([&] { REQUIRE(s, "null argument"); run_big_stack([&] { scene_fix_color(s->s); }); });
+    return guard([&] { REQUIRE(s, "null argument"); s->key_valid = false; run_big_stack([&] { scene_fix_color(s->s); }); });
 }
 
 int maray_scene_rescale(maray_scene *s, uint32_t sx, uint32_t sy)
 {
-    return guard([&] { REQUIRE(s, "null argument"); scene_rescale(s->s, sx, sy); });
+    return guard([&] { REQUIRE(s, "null argument"); s->key_valid = false; scene_rescale(s->s, sx, sy); });
 }
 
 int maray_scene_simplify(maray_scene *s)
 {
-    return guard([&] { REQUIRE(s, "null argument"); run_big_stack([&] { scene_simplify(s->s); }); });
+    return guard([&] { REQUIRE(s, "null argument"); s->key_valid = false; run_big_stack([&] { scene_simplify(s->s); }); });
+}
+
+int maray_scene_simplify_ex(maray_scene *s, uint32_t flags)
+{
+    return guard([&] {
+        REQUIRE(s, "null argument"); s->key_valid = false;
+        REQUIRE((flags & ~(uint32_t)MARAY_SIMPLIFY_MERGE_DIVISORS) == 0, "unknown simplify flag");
+        run_big_stack([&] { scene_simplify(s->s, flags); });
+    });
 }
 
 int maray_scene_compress(maray_scene *s, uint32_t *n_vars3)
 {
-    return guard([&] { REQUIRE(s, "null argument"); run_big_stack([&] { scene_compress(s->s, n_vars3); }); });
+    return guard([&] { REQUIRE(s, "null argument"); s->key_valid = false; run_big_stack([&] { scene_compress(s->s, n_vars3); }); });
 }
 
 int maray_scene_display_len(maray_scene *s, int c, uint64_t *len)
 {
     return guard([&] {
-        REQUIRE(s && len && c >= 0 && c < 3, "bad argument");
+        REQUIRE(s && len && c >= 0 && c < 3, "bad argument"); s->key_valid = false;
         run_big_stack([&] { *len = scene_display_len(s->s, c); });
     });
 }

@@ -68,7 +68,7 @@ uint64_t scene_node_count(const Scene &s, int c);
 void scene_fix_color(Scene &s);                                          // var_fixer::fix_color
 void scene_rescale(Scene &s, uint32_t sx, uint32_t sy);
 // simplify.cpp
-void scene_simplify(Scene &s);                                           // Expr::simplify on each channel
+void scene_simplify(Scene &s, uint32_t flags = 0);                       // Expr::simplify on each channel (flags: MARAY_SIMPLIFY_*)
 // compress.cpp
 void scene_compress(Scene &s, uint32_t n_vars[3]);                       // Expr::compress on each channel (n_vars: variables introduced; may be null)
 uint64_t scene_display_len(Scene &s, int c);                             // format!("{}", color[c]).chars().count()

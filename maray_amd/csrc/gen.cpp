@@ -14,7 +14,11 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <list>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -73,6 +77,76 @@ struct ScopedPin {
 
 int fail_with(int code, const std::string &m) { set_last_error(m); return code; }
 
+// ---- what the façade remembers between calls ------------------------------------------------------------------------
+// gen_to_image is called once per image (src/lib.rs:1177-1195), an animation calls it in a loop (examples/test*.rs), and
+// the reference pays its set-up -- fix_color, and for the JIT three cranelift compiles per thread -- on every call.  Here
+// a call's set-up is the lowering (chess: ~0.1 s of host work) and a context per device (streams, two module loads,
+// tables: ~50 ms), against a millisecond of rendering: so a scene's tape and its contexts stay, under the hash of the
+// scene's encoding + the textures' bytes + the back-end asked for.  The last MARAY_GEN_CACHE programs (default 4; 0: none)
+// are kept; maray_gen_cache_clear() frees them.  A context serves one call at a time: a second call for the same program
+// while the first is still rendering gets contexts of its own.
+struct GenEntry {
+    std::string key;
+    maray_tape *tape = nullptr;
+    std::map<int, maray_ctx *> idle;          // per worker slot: a context nobody is rendering with
+    bool evicted = false;
+    ~GenEntry() { for (auto &kv : idle) maray_hip_ctx_free(kv.second); maray_tape_free(tape); }
+};
+std::mutex g_gen_mutex;
+// most recently used first.  Never destroyed: at process exit the HIP runtime may be gone before a static's destructor
+// runs, and freeing a context then would call into it (device memory goes with the process anyway).
+std::list<std::shared_ptr<GenEntry>> &g_gen = *new std::list<std::shared_ptr<GenEntry>>();
+
+size_t gen_cache_capacity()
+{
+    static const size_t cap = [] {
+        const char *e = getenv("MARAY_GEN_CACHE");
+        return e ? (size_t)std::max(0, atoi(e)) : (size_t)4;
+    }();
+    return cap;
+}
+
+std::shared_ptr<GenEntry> gen_cache_find(const std::string &key)
+{
+    std::lock_guard<std::mutex> lk(g_gen_mutex);
+    for (auto it = g_gen.begin(); it != g_gen.end(); ++it)
+        if ((*it)->key == key) { g_gen.splice(g_gen.begin(), g_gen, it); return g_gen.front(); }
+    return nullptr;
+}
+
+// `fresh` becomes the entry of its key unless another call got there first (then that one is used and `fresh` goes)
+std::shared_ptr<GenEntry> gen_cache_insert(std::shared_ptr<GenEntry> fresh)
+{
+    std::vector<std::shared_ptr<GenEntry>> dead;          // freed outside the lock (contexts synchronise their streams)
+    {
+        std::lock_guard<std::mutex> lk(g_gen_mutex);
+        for (auto &e : g_gen) if (e->key == fresh->key) return e;
+        if (!gen_cache_capacity()) return fresh;          // not kept: goes with the call
+        g_gen.push_front(fresh);
+        while (g_gen.size() > gen_cache_capacity()) { g_gen.back()->evicted = true; dead.push_back(g_gen.back()); g_gen.pop_back(); }
+    }
+    return fresh;
+}
+
+maray_ctx *gen_cache_take(GenEntry &e, int slot)
+{
+    std::lock_guard<std::mutex> lk(g_gen_mutex);
+    auto it = e.idle.find(slot);
+    if (it == e.idle.end()) return nullptr;
+    maray_ctx *c = it->second;
+    e.idle.erase(it);
+    return c;
+}
+
+void gen_cache_give(GenEntry &e, int slot, maray_ctx *c)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_gen_mutex);
+        if (!e.evicted && gen_cache_capacity() && !e.idle.count(slot)) { e.idle[slot] = c; return; }
+    }
+    maray_hip_ctx_free(c);
+}
+
 template <typename F>
 int gen_guard(F f)
 {
@@ -86,6 +160,20 @@ int gen_guard(F f)
 }   // namespace
 
 extern "C" int maray_lower(const maray_scene *, const maray_lower_opts *, maray_tape **);
+namespace maray {
+void scene_cache_key(const maray_scene *s, uint64_t out[2]);      // api.cpp
+void hash128(const void *data, size_t n, uint64_t h[2]);
+}
+
+extern "C" void maray_gen_cache_clear(void)
+{
+    std::list<std::shared_ptr<GenEntry>> dead;
+    {
+        std::lock_guard<std::mutex> lk(g_gen_mutex);
+        for (auto &e : g_gen) e->evicted = true;
+        dead.swap(g_gen);
+    }
+}
 
 extern "C" int maray_gen_to_image(const maray_scene *s, const maray_texture *tex, uint32_t n_tex,
                                   const maray_gen_opts *opts, maray_report report, maray_report_fn fn, void *user,
@@ -95,12 +183,32 @@ extern "C" int maray_gen_to_image(const maray_scene *s, const maray_texture *tex
     return gen_guard([&]() -> int {
     if (w > MARAY_DOMAIN_MAX || h > MARAY_DOMAIN_MAX) return fail_with(MARAY_E_LIMIT, "image exceeds " + std::to_string(MARAY_DOMAIN_MAX) + " pixels in x or y");
     if (!w || !h) return MARAY_OK;
-    maray_tape *tape = nullptr;
-    int rc = maray_lower(s, nullptr, &tape);
-    if (rc) return rc;
-    struct TapeHolder { maray_tape *t; ~TapeHolder() { maray_tape_free(t); } } hold{tape};
+    // the program of this call: remembered from an earlier one, or lowered now
+    std::string key;
+    {
+        uint64_t h[2];
+        scene_cache_key(s, h);
+        for (uint32_t i = 0; i < n_tex; i++) {
+            const uint32_t dims[2] = {tex[i].w, tex[i].h};
+            hash128(dims, sizeof dims, h);
+            if (!tex[i].rgb && (uint64_t)tex[i].w * tex[i].h) return fail_with(MARAY_E_ARG, "null texture raster");
+            hash128(tex[i].rgb, (size_t)tex[i].w * tex[i].h * 3, h);
+        }
+        char buf[64];
+        snprintf(buf, sizeof buf, "%016llx%016llx/%u/%u", (unsigned long long)h[0], (unsigned long long)h[1], n_tex, opts ? opts->backend : (uint32_t)MARAY_BACKEND_AUTO);
+        key = buf;
+    }
+    std::shared_ptr<GenEntry> entry = gen_cache_find(key);
+    if (!entry) {
+        maray_tape *tape = nullptr;
+        int rc = maray_lower(s, nullptr, &tape);
+        if (rc) return rc;
+        auto fresh = std::make_shared<GenEntry>();
+        fresh->key = key; fresh->tape = tape;
+        entry = gen_cache_insert(fresh);
+    }
     maray_program prog;
-    maray_tape_program(tape, &prog);
+    maray_tape_program(entry->tape, &prog);
 
     int n_dev_avail = 0;
     maray_hip_device_count(&n_dev_avail);
@@ -149,12 +257,15 @@ extern "C" int maray_gen_to_image(const maray_scene *s, const maray_texture *tex
         Q.cv.notify_all();
     };
     auto worker = [&](uint32_t d) {
-        maray_ctx *ctx = nullptr;
-        int r = maray_hip_ctx_create(wrap ? (int)(d % (uint32_t)n_dev_avail) : (int)d, &prog, tex, n_tex, &co, &ctx);
+        // worker d's context: the one an earlier call left (same program, same worker slot), or a new one
+        const int dev = wrap ? (int)(d % (uint32_t)n_dev_avail) : (int)d;
+        maray_ctx *ctx = gen_cache_take(*entry, (int)d);
+        int r = ctx ? MARAY_OK : maray_hip_ctx_create(dev, &prog, tex, n_tex, &co, &ctx);
         if (!r && !share[d].empty())
             r = maray_hip_render_tiles(ctx, w, h, share[d].data(), (uint32_t)(share[d].size() / 2), rgb8, on_tile, &tu);
         const std::string msg = r ? maray_last_error() : "";      // this thread's message, re-raised on the calling thread
-        maray_hip_ctx_free(ctx);
+        if (r) maray_hip_ctx_free(ctx);                           // (a context that failed is not kept)
+        else gen_cache_give(*entry, (int)d, ctx);
         std::lock_guard<std::mutex> lk(P.m);
         if (r && !P.failed) { P.failed = r; P.err = msg; }
         P.finished++;

@@ -19,6 +19,9 @@
 //     slot allocation, ACC forwarding of results consumed by the next op.
 #include "lower.hpp"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -355,6 +358,7 @@ struct RowBounds {
     RowBounds(Dag &g_, const std::vector<uint8_t> &b, const std::vector<Mono> &m, const std::vector<Ival> &rg, uint8_t dep_bit_, uint8_t var_leaf_,
               uint8_t lo_leaf, uint8_t hi_leaf)
         : g(g_), isbool(b), mono(m), range(rg), dep_bit(dep_bit_), var_leaf(var_leaf_) {
+        sub_memo.reserve(2 * g.n.size()); memo.reserve(g.n.size()); iv_memo.reserve(g.n.size());
         c_true = g.konst(1.0); c_false = g.konst(0.0); x0 = g.leaf(lo_leaf); xmax = g.leaf(hi_leaf);
     }
     int32_t subst(int32_t i, int32_t xr) {          // i with the coordinate replaced by node xr
@@ -690,7 +694,13 @@ struct Lowerer {
     std::vector<uint8_t> in_section;            // node belongs to the section being built
     std::vector<int32_t> need;                  // Sethi-Ullman label
     std::vector<uint8_t> visited;
-    std::vector<std::vector<int32_t>> users;    // consumers inside the section (an OUT counts as user -1)
+    std::vector<uint32_t> users_off;            // consumers inside the section (an OUT counts as user -1), CSR: users of node i
+    std::vector<int32_t> users_idx;             // are users_idx[users_off[i] .. users_off[i + 1])
+    // membership by stamp instead of hash sets (the scheduler asks for the cone of every AND / OR it meets: chess lowers
+    // in a tenth of the time): a node is in the set computed last iff its stamp equals the set's epoch
+    std::vector<uint32_t> seen_stamp, cone_stamp;
+    uint32_t seen_epoch = 0, cone_epoch = 0;
+    bool in_cone(int32_t v) const { return cone_stamp[v] == cone_epoch; }
     std::unordered_map<uint64_t, uint32_t> const_index;
     std::vector<double> consts;
     std::vector<int32_t> yval_of;               // node -> y value index or -1
@@ -729,21 +739,32 @@ struct Lowerer {
         visited.assign(N, 0);
         row_depth = 0;
         used_rowguards.clear();
-        users.assign(N, {});
+        seen_stamp.assign(N, 0); cone_stamp.assign(N, 0);
+        seen_epoch = cone_epoch = 0;
+        users_off.assign(N + 1, 0);
         for (size_t i = 0; i < N; i++) {
             if (!in_section[i]) continue;
-            for (int32_t c : {g.n[i].a, g.n[i].b}) if (c >= 0 && in_section[c]) users[c].push_back((int32_t)i);
+            for (int32_t c : {g.n[i].a, g.n[i].b}) if (c >= 0 && in_section[c]) users_off[c + 1]++;
         }
-        for (auto &o : sec.outs) if (in_section[o.first]) users[o.first].push_back(-1);
+        for (auto &o : sec.outs) if (in_section[o.first]) users_off[o.first + 1]++;
+        for (size_t i = 0; i < N; i++) users_off[i + 1] += users_off[i];
+        users_idx.assign(users_off[N], 0);
+        std::vector<uint32_t> fill(users_off.begin(), users_off.end() - 1);
+        for (size_t i = 0; i < N; i++) {
+            if (!in_section[i]) continue;
+            for (int32_t c : {g.n[i].a, g.n[i].b}) if (c >= 0 && in_section[c]) users_idx[fill[c]++] = (int32_t)i;
+        }
+        for (auto &o : sec.outs) if (in_section[o.first]) users_idx[fill[o.first]++] = -1;
     }
 
     // Unvisited section nodes reachable from `root`, ascending (= topological) order.
     std::vector<int32_t> reach(int32_t root) {
         std::vector<int32_t> r, st{root};
-        std::unordered_set<int32_t> seen;
+        ++seen_epoch;
         while (!st.empty()) {
             int32_t v = st.back(); st.pop_back();
-            if (v < 0 || !in_section[v] || visited[v] || !seen.insert(v).second) continue;
+            if (v < 0 || !in_section[v] || visited[v] || seen_stamp[v] == seen_epoch) continue;
+            seen_stamp[v] = seen_epoch;
             r.push_back(v);
             st.push_back(g.n[v].a); st.push_back(g.n[v].b);
         }
@@ -753,33 +774,38 @@ struct Lowerer {
 
     // The exclusive cone of `body` with respect to its consumer `n`: the nodes of reach(body) that
     // are used by nothing but n or other nodes of the cone, i.e. that become dead when n's value is
-    // known without them.
-    std::unordered_set<int32_t> exclusive_cone(int32_t body, int32_t n, const std::vector<int32_t> &r) {
-        std::unordered_set<int32_t> in_r(r.begin(), r.end()), cone;
+    // known without them.  Returns its size; in_cone() tells its members until the next cone is computed.
+    size_t exclusive_cone(int32_t body, int32_t n, const std::vector<int32_t> &r) {
+        ++cone_epoch;
+        size_t size = 0;
         for (auto it = r.rbegin(); it != r.rend(); ++it) {      // consumers before producers
             const int32_t v = *it;
-            bool excl = !users[v].empty();
-            for (int32_t u : users[v]) {
+            bool excl = users_off[v + 1] > users_off[v];
+            for (uint32_t k = users_off[v]; k < users_off[v + 1] && excl; k++) {
+                const int32_t u = users_idx[k];
                 if (u == n && v == body) continue;
-                if (u < 0 || !cone.count(u)) { excl = false; break; }
+                if (u < 0 || !in_cone(u)) excl = false;
             }
-            if (excl) cone.insert(v);
+            if (excl) { cone_stamp[v] = cone_epoch; size++; }
         }
-        (void)in_r;
-        return cone;
+        return size;
     }
 
     // Nodes of r (= reach(v)) that feed nothing but v: they are dead when v's value is known.
-    std::unordered_set<int32_t> self_cone(int32_t v, const std::vector<int32_t> &r) {
-        std::unordered_set<int32_t> cone;
+    size_t self_cone(int32_t v, const std::vector<int32_t> &r) {
+        ++cone_epoch;
+        size_t size = 0;
         for (auto it = r.rbegin(); it != r.rend(); ++it) {
             const int32_t u0 = *it;
-            if (u0 == v) { cone.insert(v); continue; }
-            bool excl = !users[u0].empty();
-            for (int32_t u : users[u0]) if (u < 0 || !cone.count(u)) { excl = false; break; }
-            if (excl) cone.insert(u0);
+            if (u0 == v) { cone_stamp[v] = cone_epoch; size++; continue; }
+            bool excl = users_off[u0 + 1] > users_off[u0];
+            for (uint32_t k = users_off[u0]; k < users_off[u0 + 1] && excl; k++) {
+                const int32_t u = users_idx[k];
+                if (u < 0 || !in_cone(u)) excl = false;
+            }
+            if (excl) { cone_stamp[u0] = cone_epoch; size++; }
         }
-        return cone;
+        return size;
     }
 
     int region_kind(int32_t i) const {          // 1: AND (Mul/Min of booleans), 2: OR (Max of booleans)
@@ -793,12 +819,13 @@ struct Lowerer {
     // Schedules, ahead of a region, what the region's cone reads but does not own.  Only the nodes the cone reads
     // directly are visited (each brings its own sub-tree, with the regions that sub-tree deserves): walking every
     // shared node bottom-up would schedule a shared shape's factors one by one and leave nothing to guard at its root.
-    void visit_shared(const std::vector<int32_t> &r, const std::unordered_set<int32_t> &cone, Section &sec) {
+    // (the cone is the one computed last: in_cone())
+    void visit_shared(const std::vector<int32_t> &r, Section &sec) {
         std::vector<int32_t> frontier;
         for (int32_t v : r) {
-            if (!cone.count(v)) continue;
+            if (!in_cone(v)) continue;
             for (int32_t c : {g.n[v].a, g.n[v].b})
-                if (c >= 0 && in_section[c] && !visited[c] && !cone.count(c)) frontier.push_back(c);
+                if (c >= 0 && in_section[c] && !visited[c] && !in_cone(c)) frontier.push_back(c);
         }
         std::sort(frontier.begin(), frontier.end());
         frontier.erase(std::unique(frontier.begin(), frontier.end()), frontier.end());
@@ -813,9 +840,9 @@ struct Lowerer {
         row_reentry = -1;
         if (regions && !reentry && !rowub.empty() && rowub[i] >= 0 && row_depth == 0) {
             const std::vector<int32_t> r = reach(i);
-            const std::unordered_set<int32_t> cone = self_cone(i, r);
-            if (cone.size() >= MIN_ROW_REGION && cone.size() <= MAX_REGION / 2) {
-                visit_shared(r, cone, sec);                                  // shared nodes stay unconditional
+            const size_t cone = self_cone(i, r);
+            if (cone >= MIN_ROW_REGION && cone <= MAX_REGION / 2) {
+                visit_shared(r, sec);                                        // shared nodes stay unconditional
                 const size_t mark = sec.sched.size();
                 SItem sk; sk.node = rowub[i]; sk.target = i; sk.nz = 0;
                 sec.sched.push_back(sk);
@@ -839,7 +866,7 @@ struct Lowerer {
                 const int32_t bq = o ? d.a : d.b, gq = o ? d.b : d.a;
                 if (!in_section[bq] || visited[bq] || g.n[bq].op >= D_CONST) continue;
                 const std::vector<int32_t> r = reach(bq);
-                const size_t sz = exclusive_cone(bq, i, r).size();
+                const size_t sz = exclusive_cone(bq, i, r);
                 if (sz >= MIN_REGION && sz > best) { best = sz; guard = gq; body = bq; }
             }
             if (guard >= 0 && g.n[guard].op != D_CONST) {
@@ -847,9 +874,9 @@ struct Lowerer {
                 visit(guard, sec);
                 if (!visited[body]) {
                     const std::vector<int32_t> r = reach(body);
-                    const std::unordered_set<int32_t> cone = exclusive_cone(body, i, r);
-                    if (cone.size() >= MIN_REGION && cone.count(body)) {
-                        visit_shared(r, cone, sec);                               // shared nodes: computed unconditionally
+                    const size_t cone = exclusive_cone(body, i, r);
+                    if (cone >= MIN_REGION && in_cone(body)) {
+                        visit_shared(r, sec);                                     // shared nodes: computed unconditionally
                         const size_t mark = sec.sched.size();
                         SItem sk; sk.node = guard; sk.target = i; sk.nz = kind == 2;
                         sec.sched.push_back(sk);
@@ -1001,8 +1028,19 @@ struct Lowerer {
 
 void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
 {
+    // MARAY_TRACE_LOWER=1: where the time of a lowering goes (stderr)
+    const bool trace = getenv("MARAY_TRACE_LOWER") && getenv("MARAY_TRACE_LOWER")[0] == '1';
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "maray lower: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     Scene s = scene_in;
+    lap("copy scene");
     scene_fix_color(s);
+    lap("fix_color");
 
     Dag g;
     g.commute = opts.plain_cse == 0;
@@ -1010,6 +1048,7 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
     SymEval ev(s, g);
     int32_t roots[3];
     for (int c = 0; c < 3; c++) roots[c] = ev.eval(s.color[c], -1);   // outer Context::new() is empty (src/render.rs:53)
+    lap("symbolic evaluation");
 
     // Boolean typing, intervals, monotonicity on the scene's own DAG; then (optionally) the row bounds,
     // which append y-only nodes to the DAG, and the typing / intervals once more over the grown DAG.
@@ -1037,13 +1076,16 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         for (int c = 0; c < 3; c++) roots[c] = rb.map(roots[c]);
         rebalanced = rb.rebuilt;
     }
+    lap("rebalance");
     const size_t N0 = g.n.size();
+    if (row_guards) { g.map.reserve(4 * N0 + 1024); g.n.reserve(4 * N0 + 1024); }      // the row bounds grow the DAG about threefold
     const uint32_t folded_scene = g.folded;     // constant ops folded in the scene itself (the row bounds fold more)
     std::vector<int32_t> rowub;
     if (row_guards) {
         const std::vector<uint8_t> isb0 = bool_typing();
         const std::vector<Ival> iv0 = intervals(g);
         const std::vector<Mono> mono0 = monotonicity(g, iv0);
+        lap("  typing, intervals, monotone");
         RowBounds rb(g, isb0, mono0, iv0, DEP_X, D_X, D_XMIN, D_XMAX);
         rowub.assign(N0, -1);
         // sign bit provably clear and no NaN (so that "+0.0" statements compose), and finite on top
@@ -1080,6 +1122,7 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         // Second pass, over y: a guard that is built from booleans monotone in y as well is bounded over the rows
         // [YMIN, YMAX] the same way, and then holds for a rectangle of pixels -- an evaluator may compute it once for
         // several rows.  A guard that is not keeps reading Y: exact for its row, valid for that row only.
+        lap("  bounds over x");
         if (opts.no_y_spans == 0) {
             const std::vector<uint8_t> isb1 = bool_typing();
             const std::vector<Ival> iv1 = intervals(g);
@@ -1093,6 +1136,7 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         }
         rowub.resize(g.n.size(), -1);
     }
+    lap("row bounds");
 
     auto mark_reach = [&]() {                   // reachability from the channel roots
         std::vector<uint8_t> r(g.n.size(), 0);
@@ -1139,6 +1183,7 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         info.private_regions = pv.inst;
         reach = mark_reach();
     }
+    lap("census, private regions");
     const size_t N = g.n.size();
 
     Lowerer L(g);
@@ -1204,14 +1249,17 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         info.n_yvals = k;
         if (k > MARAY_MAX_INDEX + 1) throw Error{MARAY_E_LIMIT, "more than 16384 row values"};
     }
+    lap("typing, dry schedule");
     L.in_section = is_row;
     L.build(row, false);
+    lap("ROW section");
 
     std::vector<uint8_t> is_pix(N, 0);
     for (size_t i = 0; i < N; i++) if (reach[i] && is_op((int32_t)i) && !is_row[i]) is_pix[i] = 1;
     for (int c = 0; c < 3; c++) pix.outs.push_back({roots[c], (uint32_t)c});
     L.in_section = is_pix;
     L.build(pix, true);
+    lap("PIXEL section");
 
     t.consts = std::move(L.consts);
     if (t.consts.empty()) t.consts.push_back(0.0);

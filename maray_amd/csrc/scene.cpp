@@ -188,13 +188,34 @@ uint64_t scene_node_count(const Scene &s, int c) { return count_rec(s, s.color[c
 // output scene, so structural equality is index equality.
 namespace {
 
+struct PlainKey {                       // a node without context or tokens: five words (the common case by far)
+    uint64_t f[5];
+    bool operator==(const PlainKey &o) const { return memcmp(f, o.f, sizeof f) == 0; }
+};
+struct PlainKeyHash {
+    size_t operator()(const PlainKey &k) const {
+        uint64_t h = 0x9e3779b97f4a7c15ull;
+        for (uint64_t w : k.f) { h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 32; }
+        return (size_t)h;
+    }
+};
+
 struct Interner {
     Scene &out;
-    std::unordered_map<std::string, int32_t> map;
+    std::unordered_map<std::string, int32_t> map;             // Let / Decor nodes: the key spells out their context / tokens
+    std::unordered_map<PlainKey, int32_t, PlainKeyHash> plain;
 
     static void put(std::string &k, uint64_t v) { k.append((const char *)&v, 8); }
 
     int32_t intern(const Node &n, const Ctx *ctx, const std::vector<Token> *toks) {
+        if (!ctx && !toks) {
+            const PlainKey pk{{n.tag, n.u, n.app, (uint64_t)(int64_t)n.a, (uint64_t)(int64_t)n.b}};
+            auto it = plain.find(pk);
+            if (it != plain.end()) return it->second;
+            const int32_t id = out.add(n);
+            plain.emplace(pk, id);
+            return id;
+        }
         std::string k;
         k.reserve(48);
         put(k, n.tag); put(k, n.u); put(k, n.app); put(k, (uint64_t)(int64_t)n.a); put(k, (uint64_t)(int64_t)n.b);
@@ -217,7 +238,12 @@ struct Interner {
     }
 };
 
-typedef std::vector<std::pair<uint64_t, uint64_t>> Renames;   // ctx: &mut Vec<(u64,u64)> = (old, new)
+// ctx: &mut Vec<(u64,u64)> = (old, new); the reference scans it front to back (:32-34: the first entry with the old id
+// wins), so a map that keeps the first entry per old id answers the same
+struct Renames {
+    std::unordered_map<uint64_t, uint64_t> first;
+    void emplace_back(uint64_t old_id, uint64_t new_id) { first.emplace(old_id, new_id); }       // (emplace keeps an existing entry)
+};
 
 struct Fixer {
     const Scene &in;
@@ -225,7 +251,7 @@ struct Fixer {
     std::unordered_map<int32_t, uint64_t> ids;   // VarFixer::ids (:10)
     uint64_t var_count = 0;                      // VarFixer::var_count (:12)
 
-    Fixer(const Scene &in_, Scene &out) : in(in_), I{out, {}} {}
+    Fixer(const Scene &in_, Scene &out) : in(in_), I{out, {}, {}} { I.plain.reserve(in_.nodes.size()); }
 
     // verbatim structural copy (Decor tokens are carried over unfixed, :67)
     int32_t copy(int32_t e) {
@@ -261,7 +287,7 @@ struct Fixer {
         case T_ARC: return fix(n.a, ctx);                                        // :29
         case T_X: case T_Y: case T_TAU: case T_E: case T_NAT: break;             // :30
         case T_VAR:                                                              // :31-36
-            for (const auto &r : ctx) if (r.first == n.u) { m.u = r.second; break; }
+            { auto it = ctx.first.find(n.u); if (it != ctx.first.end()) m.u = it->second; }
             break;
         case T_LET: {                                                            // :49-66
             const Ctx &ic = in.ctxs[n.ctx];

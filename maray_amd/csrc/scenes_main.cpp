@@ -5,8 +5,29 @@
 #include <string>
 
 #include "maray_builders.hpp"
+#include "maray_hip.h"
 
 using namespace maray_build;
+
+// `e.simplify(mem).compress(mem)` (src/lib.rs:601-614) through the library, which works on encoded scenes: e goes in as
+// channel 0 of a scene and comes back as bytes.  merge: MARAY_SIMPLIFY_MERGE_DIVISORS (the reference's own rules do not
+// terminate on examples/chess.rs, maray_hip.h).  Exits on failure: this is a command-line tool.
+static Expr simplify_compress(const Expr &e, bool merge)
+{
+    const std::vector<uint8_t> in = encode(1, 1, {e, nat(0), nat(0)});
+    maray_scene *sc = nullptr;
+    int rc = maray_scene_from_bytes(in.data(), in.size(), &sc);
+    if (!rc) rc = maray_scene_simplify_ex(sc, merge ? MARAY_SIMPLIFY_MERGE_DIVISORS : 0);
+    if (!rc) rc = maray_scene_compress(sc, nullptr);
+    size_t len = 0;
+    std::vector<uint8_t> out;
+    if (!rc) rc = maray_scene_encode(sc, nullptr, 0, &len);
+    if (!rc) { out.resize(len); rc = maray_scene_encode(sc, out.data(), out.size(), &len); }
+    maray_scene_free(sc);
+    if (rc) { fprintf(stderr, "maray_scenes: simplify / compress: %s\n", maray_last_error()); exit(1); }
+    // header (8 bytes), channel 0, then two `Nat(0)` (4 + 8 bytes each: simplify and compress leave a natural alone)
+    return encoded(std::vector<uint8_t>(out.begin() + 8, out.end() - 24));
+}
 
 // Config 2: radial gradient, c = Sqrt(X*X + Y*Y)
 static Color radial() { Expr c = sqrt(add(mul(x(), x()), mul(y(), y()))); return {c, c, c}; }
@@ -40,9 +61,9 @@ static Color textured(uint64_t w)
     return out;
 }
 
-// examples/chess.rs:5-50 without `.simplify(mem).compress(mem)` (authoring-time tools, out of scope):
-// an 8x8 grid of quads in perspective with a chess texture.
-static Color chess_board(uint64_t size)
+// examples/chess.rs:5-50: an 8x8 grid of quads in perspective with a chess texture.  authored: with the example's
+// `.simplify(mem).compress(mem)` (:43) -- the file a user of the reference would save at this size; else the bare tree.
+static Color chess_board(uint64_t size, bool authored = false)
 {
     Point2 p = {div(x(), nat(size)), div(y(), nat(size))};
     Expr texture = set_unit_square(chess(8));
@@ -58,19 +79,23 @@ static Color chess_board(uint64_t size)
             Expr s2 = subst2(mul(inside_triangle(t.tri[1], {x(), y()}), subst2(texture, to_uv(t.tri[1], t.uv[1], {x(), y()}))), p);
             shape = set_or(shape, set_or(s1, s2));
         }
+    if (authored) shape = simplify_compress(shape, true);
     Expr c = mul(shape, nat(255));
     return {c, c, c};
 }
 
-// examples/test.rs:9-27 without simplify/compress: rounded box XOR circle
-static Color sdf(uint64_t size)
+// examples/test.rs:9-27: rounded box XOR circle; authored: with its `.simplify(mem).compress(mem)` (:21), which the
+// reference's own rules get through
+static Color sdf(uint64_t size, bool authored = false)
 {
     Point2 p = {div(x(), nat(size)), div(y(), nat(size))};
     Point2 center = {half(), half()};
     Expr tenth = div(nat(1), nat(10));
     Expr a = translate(sd_inside(sd_rounded_box({div(half(), nat(2)), half()}, {tenth, tenth, tenth, tenth})), center);
     Expr b = translate(sd_inside(sd_circle(recip(nat(3)))), center);
-    Expr c = mul(subst2(set_xor(a, b), p), nat(255));
+    Expr shape = subst2(set_xor(a, b), p);
+    if (authored) shape = simplify_compress(shape, false);
+    Expr c = mul(shape, nat(255));
     return {c, c, c};
 }
 
@@ -82,7 +107,12 @@ int main(int argc, char **argv)
            && save(d + "allops_4096.maray", 4096, 4096, all_ops(4096, 4096))
            && save(d + "textured_4096.maray", 4096, 4096, textured(4096))
            && save(d + "sdf_512.maray", 512, 512, sdf(512))
-           && save(d + "chess_board_1024.maray", 1024, 1024, chess_board(1024));
+           && save(d + "sdf_512_authored.maray", 512, 512, sdf(512, true))
+           && save(d + "chess_board_1024.maray", 1024, 1024, chess_board(1024))
+           // examples/chess.rs as the example runs it, at its own size and natively at 4096 (what simplify
+           // and compress are for -- a scene regenerated at a new size, not a stored one rescaled)
+           && save(d + "chess_authored_1024.maray", 1024, 1024, chess_board(1024, true))
+           && save(d + "chess_authored_4096.maray", 4096, 4096, chess_board(4096, true));
     if (!ok) { fprintf(stderr, "cannot write into %s\n", argv[1]); return 1; }
     return 0;
 }

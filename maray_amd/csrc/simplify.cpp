@@ -19,6 +19,7 @@ namespace {
 
 struct Simp {
     Scene &s;
+    bool merge_divisors = false;           // MARAY_SIMPLIFY_MERGE_DIVISORS (maray_hip.h): `(a/p) * 1/q` becomes `a / (p*q)`
     explicit Simp(Scene &s_) : s(s_) {}
 
     // ---- builders (src/lib.rs:836-870: sub = a + -b, div = a * 1/b) ----
@@ -317,6 +318,10 @@ struct Simp {
                 int32_t a0, a1, b0, b1;
                 const bool da = get_div(a, a0, a1), db = get_div(b, b0, b1);
                 if (da && db) return simplify(div(mul(a0, b0), mul(a1, b1)));
+                // Not in the reference: there `(a0/a1) * 1/q` takes the rule below, becomes `(a0 * 1/q) / a1`, whose numerator is the
+                // quotient a0/q again -- the two divisors change places for ever (src/simplify.rs:276-283; examples/chess.rs
+                // builds such terms: DESIGN.md section 5.1).  Merging them ends it.
+                if (da && merge_divisors && get_recip(b) >= 0) return simplify(div(a0, mul(a1, get_recip(b))));
                 if (da) return simplify(div(mul(a0, b), a1));
                 if (db) return simplify(div(mul(a, b0), b1));
             }
@@ -349,13 +354,15 @@ struct Simp {
 }   // namespace
 
 // Expr::simplify applied to the three channels (src/lib.rs:601-604).
-void scene_simplify(Scene &s)
+void scene_simplify(Scene &s, uint32_t flags)
 {
     Simp z(s);
+    z.merge_divisors = (flags & MARAY_SIMPLIFY_MERGE_DIVISORS) != 0;
     int32_t out[3];
     for (int c = 0; c < 3; c++) out[c] = z.simplify(s.color[c]);
     if (z.runaway)
-        throw Error{MARAY_E_LIMIT, "simplify: the rewrite rules do not terminate on this expression (src/simplify.rs:276-283 keeps swapping the divisors of (a/b)/c)"};
+        throw Error{MARAY_E_LIMIT, "simplify: the rewrite rules do not terminate on this expression (src/simplify.rs:276-283 keeps swapping the divisors of (a/b)/c; "
+                                 "maray_scene_simplify_ex with MARAY_SIMPLIFY_MERGE_DIVISORS merges them instead)"};
     for (int c = 0; c < 3; c++) s.color[c] = out[c];
 }
 
