@@ -265,14 +265,29 @@ def main():
             e2e['pageable'] = {'value': px_per_step / statistics.median(times) / 1e6, 'unit': 'Mpixels/s',
                                'what': 'the same into an ordinary (pageable) numpy raster: DMA into a pinned ring of the context + '
                                        'one host copy by the calling thread'}
-            t = time.perf_counter()
-            M.gen_to_image(scene, backend=backends[backend_name], out=page)
-            e2e['gen_to_image_pageable_ms'] = (time.perf_counter() - t) * 1e3
+            # the façade: what the CLI and a `RenderMethod::Hip` arm call.  First call of a program: lowering + a context
+            # (code objects from the process's table) + render + DMA; every later call with the same scene finds tape and
+            # context in the library (gen.cpp) and pays the render alone.
+            M.gen_cache_clear()
             t = time.perf_counter()
             M.gen_to_image(scene, backend=backends[backend_name], out=pin.array)
             e2e['gen_to_image_pinned_ms'] = (time.perf_counter() - t) * 1e3
-            e2e['gen_to_image_what'] = ('maray_gen_to_image, whole call: lowering + context (code objects from the process cache) + '
-                                        'render + DMA; the pageable raster is registered (pinned) for the call')
+            again = []
+            for _ in range(5):
+                t = time.perf_counter()
+                M.gen_to_image(scene, backend=backends[backend_name], out=pin.array)
+                again.append((time.perf_counter() - t) * 1e3)
+            e2e['gen_to_image_second_call_ms'] = statistics.median(again)
+            e2e['gen_to_image_equals_device_raster'] = bool(np.array_equal(pin.array, out8.cpu().numpy()))
+            parity = parity and e2e['gen_to_image_equals_device_raster']
+            t = time.perf_counter()
+            M.gen_to_image(scene, backend=backends[backend_name], out=page)
+            e2e['gen_to_image_pageable_second_call_ms'] = (time.perf_counter() - t) * 1e3
+            M.gen_cache_clear()
+            e2e['gen_to_image_what'] = ('maray_gen_to_image, whole call.  pinned_ms: first call of a program = lowering + context '
+                                        '(code objects from the process cache) + render + DMA; second_call_ms: median of 5 more calls '
+                                        'with the same scene (tape and context kept by the library); the pageable raster is '
+                                        'registered (pinned) for the call')
         pin.close()
 
     # HBM traffic per launch from the committed PMC profile of this very command (FETCH_SIZE x2 per the gfx950
@@ -282,7 +297,7 @@ def main():
     traffic = None
     executed = None
     traffic_profile = None
-    for rnd in ('r2', 'r1'):
+    for rnd in ('r3', 'r2', 'r1'):
         prof = os.path.join(ROOT, 'profiles', '%s_%s_chess4096_pmc.json' % (rnd, backend_name))
         if not os.path.exists(prof):
             continue
@@ -301,6 +316,46 @@ def main():
                     # a wave64 f64 VALU op occupies its SIMD for 4 cycles, a 32-bit one for 2: issue-port occupancy bounds
                     'valu_port_busy_frac_bounds': [2.0 / d['cycles_per_valu_inst_per_simd'], 4.0 / d['cycles_per_valu_inst_per_simd']]}
         break
+
+    # ---- N > 1 in the default (weak) mode: config 4 itself beside the headline -- BASELINE.json names chess @16384^2 for the
+    # 8-GPU run and the driver passes no --scaling -- same rows-per-rank deal (interleaved 64-row blocks, one launch),
+    # same timing discipline (warm-up, barrier + synchronize on both sides, max over ranks)
+    config4 = None
+    if n_gpus > 1 and args.scaling == 'weak':
+        sc4 = M.Scene(data)
+        sc4.rescale(16, 16)
+        t4 = sc4.lower()
+        c4 = M.Context(t4, device=local, backend=backends[backend_name])
+        lay4 = interleaved_layout(rank, n_gpus, 16384, BLOCK_ROWS)
+        blk4 = interleaved_blocks(rank, n_gpus, 16384, BLOCK_ROWS)
+        rows4 = sum(b - a for a, b in blk4)
+        buf4 = torch.empty((rows4, 16384, 3), dtype=torch.uint8, device='cuda')
+
+        def step4():
+            if lay4 is not None:
+                c4.render_blocks_device(16384, 16384, *lay4, d_rgb8=buf4.data_ptr(), stream=stream)
+                return
+            off = 0
+            for a, b in blk4:
+                c4.render_rows_device(16384, 16384, a, b, d_rgb8=buf4.data_ptr() + off * 16384 * 3, stream=stream)
+                off += b - a
+        for _ in range(args.warmup):
+            step4()
+        fence()
+        t = time.perf_counter()
+        for _ in range(args.steps):
+            step4()
+        fence()
+        dt4 = max_over_ranks(dist if world > 1 else None, time.perf_counter() - t, device='cuda')
+        ok4 = None
+        if rank == 0:       # rank 0's first row is stored row 0
+            ok4 = hashlib.sha256(buf4[0, ::16].contiguous().cpu().numpy().tobytes()).hexdigest() == golden['row_sha256']['0']
+        config4 = {'value': 16384 * 16384 * args.steps / dt4 / 1e6, 'unit': 'Mpixels/s', 'ms_per_step': dt4 / args.steps * 1e3,
+                   'scaling': 'strong', 'pixels_per_step': 16384 * 16384, 'rows_per_rank': rows4, 'bit_exact_vs_golden': ok4,
+                   'workload': 'SURVEY.md 8(d) config 4: data/chess.maray rescaled to 16384 x 16384, total work fixed, rows dealt to '
+                               'the %d ranks in interleaved 64-row blocks, one launch per rank and step, no collective' % n_gpus}
+        c4.close()
+        del buf4
 
     cpu = None
     cpu_jit = None
@@ -367,6 +422,7 @@ def main():
                                                      'boolean algebra on lane masks (scalar unit)'},
                          'executed': executed},
             'end_to_end': e2e,
+            'config4_strong': config4,
             'cold_first_render_ms': cold,
             'cpu_baseline': cpu,
             'cpu_baseline_jit': cpu_jit,

@@ -302,6 +302,12 @@ class PinnedRaster:
         self._p = p
         self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(h, w, 3))
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def close(self):
         if getattr(self, '_p', None):
             self.array = None

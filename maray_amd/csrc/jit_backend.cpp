@@ -54,7 +54,11 @@ extern "C" const char maray_embedded_device_math_h[];
 extern "C" const char maray_embedded_libm_h[];
 extern "C" const char maray_embedded_libm_tables_h[];
 
-static const char JIT_OPTIONS[] = "--offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -std=c++17";     // of jit_compile; part of the cache key
+// of jit_compile; part of the cache key.  -structurizecfg-skip-uniform-regions: the generated kernels branch on wave-uniform
+// conditions throughout (lane masks tested on the scalar unit), and the branch table of a guarded OR-reduction (an asm
+// goto inside a loop) only survives when the structurizer leaves uniform regions alone: without the option the back end
+// rewrites the table's edges into tests of flags nobody sets
+static const char JIT_OPTIONS[] = "--offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -std=c++17 -mllvm -structurizecfg-skip-uniform-regions";
 
 namespace maray {
 
@@ -119,8 +123,132 @@ struct GuardPlan {
     std::vector<std::vector<uint32_t>> members;  // per derived guard: the bits it is the OR of
 };
 
+// ---- guarded OR-reductions of the PIXEL section -------------------------------------------------------------------
+// A scene that paints shape over shape is `max(shape, max(shape, ...))` of booleans: after the lowering a balanced OR
+// tree whose leaves are conjunctions, each inside a SKIPZ region that a rectangle guard (one bit of the guard words)
+// switches off, with group guards and "all lanes already covered" SKIPNZ regions around the sub-trees.  Walked as
+// written, a pass of 64 pixels tests that whole skeleton -- chess: ~85 scalar instructions of bit tests, branches and
+// mask moves for the 13 top-level groups alone, whatever is set -- to enter the 2-4 shapes whose bit is set; the busy
+// tiles are bound by exactly that unit.  So the tree is recognised and evaluated from the other end: the OR of the
+// leaves WHOSE BIT IS SET, found with s_ff1 on the masked guard words and reached through a branch table -- cost
+// proportional to the set bits, not to the tree.  Legal because OR on {+0.0, 1.0} (masks) is associative and commutative,
+// a leaf whose bit is clear is +0.0 over the whole rectangle (that is what its guard says), and an evaluator may ignore
+// any SKIP op: the group guards and the SKIPNZ regions of the tree are not consulted at all (the loop leaves as soon as
+// every lane is covered, which is what the SKIPNZ regions were for).
+struct RedPlan {
+    enum Role : uint8_t { NONE = 0, LEAF_SKIP, LEAF_END, INNER, ROOT, IGNORED_SKIP };
+    struct Red {
+        uint32_t root = 0;
+        std::vector<uint32_t> leaf_skip, leaf_end, leaf_bit;        // guarded leaves: their SKIPZ op, their last op, their guard bit
+    };
+    std::vector<uint8_t> role;          // per op
+    std::vector<int32_t> red;           // per op with a role: its reduction
+    std::vector<int32_t> leaf;          // LEAF_SKIP / LEAF_END: index into Red::leaf_*
+    std::vector<Red> reds;
+    bool empty() const { return reds.empty(); }
+};
+
+// is_bool: per op, the emitter's own typing (a dry run).  guard g of a SKIPZ on y value guard_first + g has bit gp.pos[g]
+// (or is derived: no bit).  A tree qualifies when it has at least `min_leaves` guarded leaves.
+RedPlan plan_reductions(const uint64_t *ops, uint32_t n, uint32_t n_slots, const std::vector<uint8_t> &is_bool, uint32_t guard_first,
+                        const GuardPlan &gp, uint32_t min_leaves = 4)
+{
+    RedPlan rp;
+    rp.role.assign(n, RedPlan::NONE); rp.red.assign(n, -1); rp.leaf.assign(n, -1);
+    // producers of every op's operands (ops write slots and ACC), use counts, and the regions that end at an op
+    std::vector<int32_t> pa(n, -1), pb(n, -1), slot(n_slots, -1);
+    std::vector<uint32_t> uses(n, 0);                       // reads by computing ops and OUTs
+    std::vector<std::vector<uint32_t>> skips_ending(n), skips_on(n);       // per op: the SKIP ops that end at it / that it guards
+    int32_t acc = -1;
+    auto prod = [&](uint32_t r) -> int32_t {
+        if (MARAY_REF_KIND(r) == MARAY_K_SLOT) return slot[MARAY_REF_INDEX(r)];
+        if (MARAY_REF_KIND(r) == MARAY_K_SPEC && MARAY_REF_INDEX(r) == MARAY_SPEC_ACC) return acc;
+        return -1;
+    };
+    for (uint32_t i = 0; i < n; i++) {
+        const uint64_t ins = ops[i];
+        const uint32_t op = MARAY_INS_OP(ins), dst = MARAY_INS_DST(ins);
+        if (op == MARAY_OP_NOP) continue;
+        if (op != MARAY_OP_TEXDIM) pa[i] = prod(MARAY_INS_A(ins));
+        if (op == MARAY_OP_SKIPZ || op == MARAY_OP_SKIPNZ) {
+            skips_ending[i + MARAY_INS_AUX(ins)].push_back(i);
+            if (pa[i] >= 0) skips_on[pa[i]].push_back(i);
+            continue;
+        }
+        if (pa[i] >= 0) uses[pa[i]]++;
+        if (op == MARAY_OP_OUT) continue;
+        if (op >= MARAY_OP_ADD && op <= MARAY_OP_APP) { pb[i] = prod(MARAY_INS_B(ins)); if (pb[i] >= 0) uses[pb[i]]++; }
+        acc = (int32_t)i;
+        if (dst != MARAY_DST_NONE) slot[dst] = (int32_t)i;
+    }
+    // the rectangle-guarded region that ends at op e (outermost SKIPZ on a guard with a bit of its own), or -1
+    auto guarded_region = [&](uint32_t e, uint32_t *bit) -> int32_t {
+        for (uint32_t s : skips_ending[e]) {         // ascending: outermost first
+            const uint32_t g = MARAY_INS_A(ops[s]);
+            if (MARAY_INS_OP(ops[s]) != MARAY_OP_SKIPZ || MARAY_REF_KIND(g) != MARAY_K_YVAL || MARAY_REF_INDEX(g) < guard_first) continue;
+            const uint32_t k = MARAY_REF_INDEX(g) - guard_first;
+            if (k >= gp.pos.size() || gp.pos[k] < 0) continue;
+            *bit = (uint32_t)gp.pos[k];
+            return (int32_t)s;
+        }
+        return -1;
+    };
+    std::vector<uint8_t> inside_leaf(n, 0);
+    for (int32_t R = (int32_t)n - 1; R >= 0; R--) {         // outermost trees first
+        if (MARAY_INS_OP(ops[R]) != MARAY_OP_MAX || !is_bool[R] || rp.role[R] != RedPlan::NONE || inside_leaf[R]) continue;
+        std::vector<uint32_t> inner, st{(uint32_t)R};
+        RedPlan::Red red;
+        red.root = (uint32_t)R;
+        bool ok = true;
+        while (!st.empty() && ok) {
+            const uint32_t v = st.back(); st.pop_back();
+            inner.push_back(v);
+            for (int32_t p : {pa[v], pb[v]}) {
+                if (p < 0) continue;                                               // a literal or a y value: a free leaf
+                if (MARAY_INS_OP(ops[p]) == MARAY_OP_MAX && is_bool[p] && uses[p] == 1 && rp.role[p] == RedPlan::NONE) { st.push_back((uint32_t)p); continue; }
+                uint32_t bit = 0;
+                const int32_t s = (is_bool[p] && uses[p] == 1) ? guarded_region((uint32_t)p, &bit) : -1;
+                if (s < 0) continue;                                               // a free leaf: evaluated where it stands
+                for (uint32_t j = (uint32_t)s; j <= (uint32_t)p && ok; j++) ok = rp.role[j] == RedPlan::NONE && !inside_leaf[j];
+                red.leaf_skip.push_back((uint32_t)s); red.leaf_end.push_back((uint32_t)p); red.leaf_bit.push_back(bit);
+            }
+        }
+        // a part of the tree may guard a SKIP op only if that op goes with the tree (it ends at an OR of the tree: the
+        // "every lane is covered already" regions); any other reader of its value needs the value
+        {
+            std::vector<uint32_t> parts = inner;
+            parts.insert(parts.end(), red.leaf_end.begin(), red.leaf_end.end());
+            for (uint32_t v : parts) {
+                if (v == (uint32_t)R) continue;
+                for (uint32_t sk : skips_on[v]) {
+                    const uint32_t end = sk + MARAY_INS_AUX(ops[sk]);
+                    ok = ok && std::find(inner.begin(), inner.end(), end) != inner.end();
+                }
+            }
+        }
+        if (!ok || red.leaf_end.size() < min_leaves) continue;
+        // two leaves on one bit (a shape two sub-trees share) cannot be told apart by the dispatch: leave such a tree alone
+        { std::vector<uint32_t> b = red.leaf_bit; std::sort(b.begin(), b.end()); if (std::adjacent_find(b.begin(), b.end()) != b.end()) continue; }
+        const int32_t id = (int32_t)rp.reds.size();
+        for (uint32_t v : inner) {
+            rp.role[v] = v == (uint32_t)R ? RedPlan::ROOT : RedPlan::INNER; rp.red[v] = id;
+            for (uint32_t s : skips_ending[v]) { rp.role[s] = RedPlan::IGNORED_SKIP; rp.red[s] = id; }
+        }
+        for (size_t k = 0; k < red.leaf_end.size(); k++) {
+            const uint32_t s = red.leaf_skip[k], e = red.leaf_end[k];
+            for (uint32_t j = s; j <= e; j++) inside_leaf[j] = 1;
+            // regions that end at the leaf's last op and start before its guard's SKIPZ would enclose it: ignored as well
+            for (uint32_t q : skips_ending[e]) if (q < s) { rp.role[q] = RedPlan::IGNORED_SKIP; rp.red[q] = id; }
+            rp.role[s] = RedPlan::LEAF_SKIP; rp.role[e] = RedPlan::LEAF_END;
+            rp.red[s] = rp.red[e] = id; rp.leaf[s] = rp.leaf[e] = (int32_t)k;
+        }
+        rp.reds.push_back(std::move(red));
+    }
+    return rp;
+}
+
 struct Emitter {
-    enum Kind { DBL, BOOL, NEGBOOL };   // NEGBOOL: value is -(b) in {-0.0, -1.0}, b = the named mask
+    enum Kind { DBL, BOOL, NEGBOOL, REDPART };   // NEGBOOL: value is -(b) in {-0.0, -1.0}, b = the named mask; REDPART: part of a guarded OR-reduction (RedPlan): no value of its own
     struct Val {
         Kind kind = DBL;
         std::string d;   // name / literal of the double, empty until materialised
@@ -157,7 +285,17 @@ struct Emitter {
     std::string td = "double", tm = "mr_mask";  // types of a value / a boolean in the generated text ("mr_d" / "mr_m": four pixels per lane)
     std::vector<double> ktab_vals;
     std::unordered_map<uint64_t, uint32_t> ktab_block;
+    const RedPlan *rplan = nullptr;             // PIXEL: the guarded OR-reductions of the section being emitted (null: walk the tree as written)
+    uint32_t red_serial = 0;                    // (names of the labels: a section may be emitted more than once into one kernel)
     explicit Emitter(const maray_program &p) : P(p) {}
+
+    // word wi of the guard words of the rectangle at hand: an SGPR pair by name (<= 12 words); beyond, lane wi % 64 of a
+    // per-lane value (one v_readlane pair)
+    std::string guard_word(uint32_t wi) const {
+        if (guard_words <= gw_inline_max) return "gq" + std::to_string(wi);
+        if (!gw_lane_base.empty()) return "mr_lane64(mr_gt0, " + gw_lane_base + " + " + std::to_string(wi) + "u)";
+        return "mr_lane64(mr_gt" + std::to_string(wi / 64) + ", " + std::to_string(wi % 64) + "u)";
+    }
 
     void section(const uint64_t *ops, uint32_t n, uint32_t n_slots, bool pixel, const char *prefix)
     {
@@ -200,7 +338,7 @@ struct Emitter {
             }
         };
         // the double form of a value, materialising it once if needed
-        struct Open { uint32_t end; bool as_bool; bool nz; uint32_t id; };
+        struct Open { uint32_t end; bool as_bool; bool nz; uint32_t id; bool leaf; };      // leaf: the block of a reduction's leaf (no variable, no else)
         std::vector<Open> open;     // SKIPZ / SKIPNZ regions being emitted, innermost last
         uint32_t next_scope = 1;
         auto dbl = [&](Val *v, const char *hint, uint32_t i, int which) -> std::string {
@@ -220,10 +358,25 @@ struct Emitter {
         };
 
         std::vector<uint8_t> forced(n, 0);      // op ends a region known at compile time to be skipped: its value is 0 (1) or 1 (2)
+        // guarded OR-reductions (RedPlan): a leaf's text is collected aside and placed behind the branch table at the root
+        const RedPlan *rp = (pixel && rplan && !rplan->empty() && !assume_guards_zero && !ignore_row_guards) ? rplan : nullptr;
+        std::vector<std::vector<std::string>> red_leaf_text(rp ? rp->reds.size() : 0);
+        std::vector<std::vector<std::string>> red_free(rp ? rp->reds.size() : 0);
+        if (rp) for (size_t k = 0; k < rp->reds.size(); k++) red_leaf_text[k].resize(rp->reds[k].leaf_end.size());
+        std::string out_saved;                  // the section's text while a leaf's is being collected in `out`
+        const uint32_t serial = red_serial++;
         for (uint32_t i = 0; i < n; i++) {
             const uint64_t ins = ops[i];
             const uint32_t op = MARAY_INS_OP(ins), aux = MARAY_INS_AUX(ins), dst = MARAY_INS_DST(ins);
             if (op == MARAY_OP_NOP) continue;
+            const uint8_t role = rp ? rp->role[i] : (uint8_t)RedPlan::NONE;
+            if (role == RedPlan::IGNORED_SKIP) continue;            // legal: an evaluator may ignore any SKIP op
+            if (role == RedPlan::LEAF_SKIP) {
+                out_saved.swap(out);                                // (out_saved was empty: leaves do not nest)
+                open.push_back(Open{i + aux, true, false, next_scope++, true});
+                ktab_block.clear();
+                continue;
+            }
             Val *va = (op != MARAY_OP_TEXDIM && !forced[i]) ? ref(MARAY_INS_A(ins), 0) : nullptr;
             if (op == MARAY_OP_SKIPZ || op == MARAY_OP_SKIPNZ) {
                 // if (some lane still needs it) { region } else result = 0 / 1;  -- a scalar branch on the ballot
@@ -264,12 +417,7 @@ struct Emitter {
                 if (row_guard && !nz && guard_words && MARAY_REF_INDEX(gref) >= guard_first) {
                     // a row bound: one bit of a guard word that sits in an SGPR since the kernel's prologue
                     const uint32_t g = MARAY_REF_INDEX(gref) - guard_first;
-                    // a guard word: an SGPR pair by name (<= 12 words); beyond, lane wi % 64 of a per-lane value (one v_readlane pair)
-                    auto word = [&](uint32_t wi) {
-                        if (guard_words <= gw_inline_max) return "gq" + std::to_string(wi);
-                        if (!gw_lane_base.empty()) return "mr_lane64(mr_gt0, " + gw_lane_base + " + " + std::to_string(wi) + "u)";
-                        return "mr_lane64(mr_gt" + std::to_string(wi / 64) + ", " + std::to_string(wi % 64) + "u)";
-                    };
+                    auto word = [&](uint32_t wi) { return guard_word(wi); };
                     // tests on 32-bit halves of the words: s_and_b32 sets SCC and the branch follows (a 64-bit test is
                     // s_and + s_cmp_u64 + the branch, on the unit that bounds the busy tiles)
                     std::vector<uint64_t> m(guard_words, 0);
@@ -298,14 +446,14 @@ struct Emitter {
                 // several regions may end at one op (a row-level guard around a wave-level one): one variable
                 bool typed_bool = as_bool;
                 bool declared = false;
-                for (const Open &o : open) if (o.end == end) { declared = true; typed_bool = o.as_bool; }
+                for (const Open &o : open) if (o.end == end && !o.leaf) { declared = true; typed_bool = o.as_bool; }
                 if (!declared) out += typed_bool ? "    " + tm + " b" + std::string(name) + ";\n" : "    " + td + " " + std::string(name) + ";\n";
                 // A region behind a rectangle guard is entered rarely (chess: 4 of the 15 a pass tests): unlikely, so that the block
                 // placement keeps the skip path as the fall-through and moves the bodies out of line (taken jumps stall on
                 // instruction fetch).  A wave-level region of the PIXEL section sits inside a shape whose guard let the wavefront
                 // in, and is entered nine times in ten (18 of 20 per pass): likely (board crop 82.3 -> 81.6 us).
                 out += "    if (__builtin_expect(" + cond + (pixel && !row_guard ? ", 1)) {\n" : ", 0)) {\n");
-                open.push_back(Open{end, typed_bool, nz, next_scope++});
+                open.push_back(Open{end, typed_bool, nz, next_scope++, false});
                 ktab_block.clear();
                 continue;
             }
@@ -345,6 +493,7 @@ struct Emitter {
                 return a == "MR_NONE" ? "MR_ALL" : (a == "MR_ALL" ? "MR_NONE" : "~" + a);
             };
             if (forced[i]) be = forced[i] == 2 ? "MR_ALL" : "MR_NONE";     // exactly +0.0 / 1.0: a boolean whatever the op
+            else if (role == RedPlan::INNER || role == RedPlan::ROOT) ;     // an OR of a reduction: below
             else
             switch (op) {
             case MARAY_OP_MOV: r = *va; break;
@@ -387,7 +536,66 @@ struct Emitter {
             case MARAY_OP_TEXDIM: e = "mr_texdim(tex, " + std::to_string(aux) + "u)"; break;
             default: throw Error{MARAY_E_ARG, "invalid opcode"};
             }
-            const bool closes = !open.empty() && open.back().end == i;
+            if (role == RedPlan::INNER || role == RedPlan::ROOT) {
+                // an OR of the tree: its operands are parts of the tree (nothing to do) or free leaves (OR-ed in at the root)
+                const int32_t id = rp->red[i];
+                for (Val *v : {va, vb}) {
+                    if (!v || v->kind == REDPART) continue;
+                    const std::string m = v->kind == BOOL ? v->b : "mr_ne0(" + dbl(v, "m", i, v == vb) + ")";
+                    if (m != "MR_NONE") red_free[id].push_back(m);
+                }
+                if (role == RedPlan::INNER) {
+                    r.kind = REDPART;
+                    vals[i] = r;
+                    is_bool_op[i] = 1;
+                    acc = (int)i;
+                    if (dst != MARAY_DST_NONE) slot[dst] = (int)i;
+                    continue;
+                }
+                // the root: the OR of the free leaves and of the guarded leaves whose bit is set in the rectangle's guard words.
+                // Per word: the reduction's bits of it, lowest first (s_ff1), each reached through a table of branches that
+                // follows an s_setpc (s_getpc returns the address of the instruction after itself: the table starts 12 bytes on)
+                const RedPlan::Red &red = rp->reds[id];
+                const std::string rid = std::to_string(serial) + "_" + std::to_string(id);
+                const std::string racc = "mr_racc" + rid;
+                out += "    mr_mask " + racc + " = MR_NONE";
+                for (const std::string &m : red_free[id]) out += " | " + m;
+                out += ";\n";
+                for (uint32_t wi = 0; wi < guard_words; wi++) {
+                    std::vector<int32_t> leaf_of_bit(64, -1);
+                    uint64_t mask = 0;
+                    int top = -1;
+                    for (size_t k = 0; k < red.leaf_bit.size(); k++)
+                        if (red.leaf_bit[k] / 64 == wi) { leaf_of_bit[red.leaf_bit[k] % 64] = (int32_t)k; mask |= 1ull << (red.leaf_bit[k] % 64); top = std::max(top, (int)(red.leaf_bit[k] % 64)); }
+                    if (!mask) continue;
+                    char hex[32];
+                    snprintf(hex, sizeof hex, "0x%llxull", (unsigned long long)mask);
+                    const std::string w = std::to_string(wi), next = "mr_rn" + rid + "_" + w;
+                    out += "    for (mr_mask mr_rm = " + guard_word(wi) + " & " + hex + "; mr_rm != 0ull && " + racc + " != MR_ALL; ) {\n"
+                           "        const unsigned mr_rk = (unsigned)__builtin_ctzll(mr_rm);\n"
+                           "        mr_rm &= mr_rm - 1ull;\n"
+                           "        asm goto(\"s_getpc_b64 s[20:21]\\n\\ts_add_u32 s20, s20, %0\\n\\ts_addc_u32 s21, s21, 0\\n\\ts_setpc_b64 s[20:21]\"";
+                    std::string labels;
+                    int n_labels = 0;
+                    std::vector<int> label_no(red.leaf_bit.size(), -1);
+                    for (int b = 0; b <= top; b++) {
+                        int ln;
+                        if (leaf_of_bit[b] < 0) ln = 0;
+                        else { if (label_no[leaf_of_bit[b]] < 0) { label_no[leaf_of_bit[b]] = ++n_labels; labels += ", mr_rl" + rid + "_" + std::to_string(leaf_of_bit[b]); } ln = label_no[leaf_of_bit[b]]; }
+                        out += "\n                 \"\\n\\ts_branch %l" + std::to_string(1 + ln) + "\"";
+                    }
+                    out += "\n                 : : \"s\"(mr_rk * 4u + 12u) : \"s20\", \"s21\", \"scc\" : " + next + labels + ");\n"
+                           "        goto " + next + ";              // (not reached: the asm always jumps; `unreachable` here crashes the back end)\n";
+                    for (int b = 0; b <= top; b++) {
+                        if (leaf_of_bit[b] < 0) continue;
+                        out += "    mr_rl" + rid + "_" + std::to_string(leaf_of_bit[b]) + ": {\n" + red_leaf_text[id][leaf_of_bit[b]] + "    } goto " + next + ";\n";
+                    }
+                    out += "    " + next + ": ;\n    }\n";
+                }
+                ktab_block.clear();
+                be = racc;
+            }
+            const bool closes = !open.empty() && open.back().end == i && !open.back().leaf;
             if (closes) {
                 ktab_block.clear();
                 // the AND / OR that ends a region: assign the variable declared before the `if`
@@ -405,7 +613,7 @@ struct Emitter {
                     out += "    " + self + " = " + ee + ";\n    } else " + self + (o.nz ? " = 1.0;\n" : " = 0.0;\n");
                     r.kind = DBL; r.d = self;
                 }
-                while (!open.empty() && open.back().end == i) {     // enclosing regions that end here too
+                while (!open.empty() && open.back().end == i && !open.back().leaf) {     // enclosing regions that end here too
                     const Open o2 = open.back();
                     open.pop_back();
                     out += o.as_bool ? "    } else b" + self + (o2.nz ? " = MR_ALL;\n" : " = MR_NONE;\n")
@@ -421,6 +629,25 @@ struct Emitter {
             } else if (!e.empty()) {
                 out += "    const " + td + " " + self + " = " + e + ";\n";
                 r.kind = DBL; r.d = self;
+            }
+            if (role == RedPlan::LEAF_END) {
+                // the leaf's block ends: its mask joins the reduction's accumulator; the text goes to its place behind the table
+                if (open.empty() || !open.back().leaf || open.back().end != i) throw Error{MARAY_E_INTERNAL, "reduction leaf out of step"};
+                open.pop_back();
+                const int32_t id = rp->red[i];
+                const std::string m = r.kind == BOOL ? r.b : "mr_ne0(" + dbl(&r, "m", i, 0) + ")";
+                out += "    mr_racc" + std::to_string(serial) + "_" + std::to_string(id) + " |= " + m + ";\n";
+                red_leaf_text[id][rp->leaf[i]].swap(out);
+                out.swap(out_saved);
+                out_saved.clear();
+                ktab_block.clear();
+                r = Val();
+                r.kind = REDPART;
+                vals[i] = r;
+                is_bool_op[i] = 1;
+                acc = (int)i;
+                if (dst != MARAY_DST_NONE) slot[dst] = (int)i;
+                continue;
             }
             vals[i] = r;
             is_bool_op[i] = r.kind == BOOL;
@@ -863,6 +1090,7 @@ std::string jit_source(const maray_program &P, int min_waves)
         for (uint32_t j = 0; j < n_gwords; j++)
             s += "    mr_mask gq" + std::to_string(j) + " = mr_lane64(mr_gv, t * " + nw + "u + " + std::to_string(j) + "u);\n";
     if (defer) s += "    ((volatile unsigned *)mr_slow)[mr_wv] = 0u;\n    bool mr_slow_tile = false;\n";
+    RedPlan reductions;
     if (!E.ignore_row_guards) {         // dry run: which ops yield lane masks
         Emitter D(P);
         D.ignore_row_guards = true;
@@ -870,6 +1098,9 @@ std::string jit_source(const maray_program &P, int min_waves)
         D.ybool = E.ybool;
         D.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
         E.bool_hint = D.is_bool_op;
+        // OR trees of guarded shapes: evaluated from their set guard bits (RedPlan).  MARAY_JIT_REDUCE=0: walked as written (ablation)
+        const char *e_ = getenv("MARAY_JIT_REDUCE");
+        if (!(e_ && e_[0] == '0')) reductions = plan_reductions(P.pix_ops, P.n_pix_ops, P.n_pix_slots, D.is_bool_op, n_ynum, plan);
     }
     // what opens a pass of either width: the tables made opaque (LICM would hoist every constant and y value out of the
     // loops and spill them), the pixel coordinates, the outputs
@@ -993,7 +1224,9 @@ std::string jit_source(const maray_program &P, int min_waves)
              "    double o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"
              "    float mr_defer = 0.0f;\n"
              "    (void)X; (void)mr_defer;\n";
+        E.rplan = &reductions;
         E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+        E.rplan = nullptr;
         s += defer_pass +
              "    const unsigned pk = mr_cast_u8(o0) | (mr_cast_u8(o1) << 8) | (mr_cast_u8(o2) << 16);\n"
              "    if (mr_fast) {\n"
@@ -1044,7 +1277,7 @@ void jit_compile(const std::string &src, std::vector<char> &code, std::string &l
     const char *names[] = {"device_math.h", "maray_libm.h", "maray_libm_tables.h"};
     RTC_TRY(hiprtcCreateProgram(&prog, src.c_str(), "maray_jit.hip", 3, headers, names));
     const char *olevel = getenv("MARAY_JIT_OPT");          // "-O1" builds faster (1.7 against 2.6 s for chess, kernel 37.4 against 35.6 us)
-    std::vector<const char *> opts = {"--offload-arch=gfx950", (olevel && olevel[0] == '-') ? olevel : "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17"};
+    std::vector<const char *> opts = {"--offload-arch=gfx950", (olevel && olevel[0] == '-') ? olevel : "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-mllvm", "-structurizecfg-skip-uniform-regions"};
     std::vector<std::string> extra;                        // MARAY_JIT_EXTRA="-mllvm -some-flag ...": measurement knob
     if (const char *e_ = getenv("MARAY_JIT_EXTRA")) { std::istringstream in(e_); for (std::string w; in >> w;) extra.push_back(w); }
     for (const std::string &w : extra) opts.push_back(w.c_str());

@@ -63,7 +63,7 @@ int main(int argc, char **argv)
     hiprtcProgram prog;
     if (create(&prog, src.c_str(), "maray_jit.hip", 3, headers, names) != 0) return 6;
     const char *olevel = argc > 4 && argv[4][0] == '-' ? argv[4] : "-O3";
-    std::vector<const char *> opts = {"--offload-arch=gfx950", olevel, "-ffp-contract=off", "-fno-fast-math", "-std=c++17"};       // = jit_compile (jit_backend.cpp)
+    std::vector<const char *> opts = {"--offload-arch=gfx950", olevel, "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-mllvm", "-structurizecfg-skip-uniform-regions"};       // = jit_compile (jit_backend.cpp)
     std::vector<std::string> extra;                        // MARAY_JIT_EXTRA, inherited from the caller's environment
     if (const char *e_ = getenv("MARAY_JIT_EXTRA")) { std::istringstream in(e_); for (std::string w; in >> w;) extra.push_back(w); }
     for (const std::string &w : extra) opts.push_back(w.c_str());

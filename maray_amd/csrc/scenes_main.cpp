@@ -101,18 +101,32 @@ static Color sdf(uint64_t size, bool authored = false)
 
 int main(int argc, char **argv)
 {
-    if (argc != 2) { fprintf(stderr, "usage: maray_scenes OUTDIR\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: maray_scenes OUTDIR [SCENE ...]      (no SCENE: all of them)\n"); return 2; }
     const std::string d = std::string(argv[1]) + "/";
-    bool ok = save(d + "radial_1024.maray", 1024, 1024, radial())
-           && save(d + "allops_4096.maray", 4096, 4096, all_ops(4096, 4096))
-           && save(d + "textured_4096.maray", 4096, 4096, textured(4096))
-           && save(d + "sdf_512.maray", 512, 512, sdf(512))
-           && save(d + "sdf_512_authored.maray", 512, 512, sdf(512, true))
-           && save(d + "chess_board_1024.maray", 1024, 1024, chess_board(1024))
-           // examples/chess.rs as the example runs it, at its own size and natively at 4096 (what simplify
-           // and compress are for -- a scene regenerated at a new size, not a stored one rescaled)
-           && save(d + "chess_authored_1024.maray", 1024, 1024, chess_board(1024, true))
-           && save(d + "chess_authored_4096.maray", 4096, 4096, chess_board(4096, true));
-    if (!ok) { fprintf(stderr, "cannot write into %s\n", argv[1]); return 1; }
+    auto want = [&](const char *name) {
+        if (argc == 2) return true;
+        for (int i = 2; i < argc; i++) if (name == std::string(argv[i])) return true;
+        return false;
+    };
+    struct Item { const char *name; uint32_t w, h; Color (*make)(); };
+    const Item items[] = {
+        {"radial_1024", 1024, 1024, [] { return radial(); }},
+        {"allops_4096", 4096, 4096, [] { return all_ops(4096, 4096); }},
+        {"textured_4096", 4096, 4096, [] { return textured(4096); }},
+        {"sdf_512", 512, 512, [] { return sdf(512); }},
+        {"sdf_512_authored", 512, 512, [] { return sdf(512, true); }},
+        {"chess_board_1024", 1024, 1024, [] { return chess_board(1024); }},
+        // examples/chess.rs as the example runs it, at its own size and natively at 4096 (what simplify
+        // and compress are for -- a scene regenerated at a new size, not a stored one rescaled)
+        {"chess_authored_1024", 1024, 1024, [] { return chess_board(1024, true); }},
+        {"chess_authored_4096", 4096, 4096, [] { return chess_board(4096, true); }},
+    };
+    int written = 0;
+    for (const Item &it : items) {
+        if (!want(it.name)) continue;
+        if (!save(d + it.name + ".maray", it.w, it.h, it.make())) { fprintf(stderr, "cannot write into %s\n", argv[1]); return 1; }
+        written++;
+    }
+    if (argc > 2 && written != argc - 2) { fprintf(stderr, "maray_scenes: unknown scene name\n"); return 2; }
     return 0;
 }

@@ -129,3 +129,28 @@ def test_rules_that_do_not_terminate_are_an_error_not_a_crash():
     with pytest.raises(M.MarayError) as e:
         simplified(mul(div(x(), nat(2)), r(y())))
     assert 'do not terminate' in str(e.value)
+
+
+def test_the_reference_rules_do_not_terminate_on_examples_chess_and_merged_divisors_do():
+    """The term that stops `/root/reference/examples/chess.rs:43`: `to_uv` of grid cell (0,0), triangle 2, arrives at the
+    Mul rules (src/simplify.rs:247-327) as `1/8 * -((10400 * (y/64 - 43/5)) / 6240)`.  By hand: the Neg moves out (:265-270),
+    `1/8 * B` with B = M/6240 becomes B / 8 (:271-276), its left operand is a quotient so :277-283 makes it
+    `(M * 1/8) / 6240`, whose numerator is the quotient M/8 -- no rule merges the two divisors, :277-283 fires again with
+    8 and 6240 swapped, for ever.  The restated rules report it (MARAY_E_LIMIT); with MARAY_SIMPLIFY_MERGE_DIVISORS the
+    quotient of a quotient is one quotient, `M / 49920`, which constant_reduction (src/constant_reduction.rs:33-48) brings
+    to `(5 * ...) / 24`.  Values before and after agree (the oracle evaluates both)."""
+    import pytest
+    from marayb import recip as r
+    from oracle_ffi import eval1
+    term = mul(r(nat(8)), neg(div(mul(nat(10400), sub(div(y(), nat(64)), div(nat(43), nat(5)))), nat(6240))))
+    with pytest.raises(M.MarayError) as e:
+        simplified(term)
+    assert e.value.code == -7 and 'do not terminate' in str(e.value)
+    s = M.Scene(encode((8, 8), [term, term, term]))
+    s.simplify(merge_divisors=True)
+    got = decode(s.encode())[1][0]
+    inner = sub(div(y(), nat(64)), div(nat(43), nat(5)))
+    assert got == neg(div(mul(nat(5), inner), nat(24))), got
+    for yv in (0.0, 3.0, 550.4, 1023.0):
+        a, b = eval1(term, 0.0, yv), eval1(got, 0.0, yv)
+        assert abs(a - b) <= 4e-16 * max(1.0, abs(a)), (yv, a, b)
