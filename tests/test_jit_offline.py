@@ -29,22 +29,35 @@ def test_all_ops_scene_compiles_for_gfx950():
     assert blob[:4] == b'\x7fELF' and len(blob) > 4096
 
 
-def test_chess_uses_the_pure_bounded_step_sin(chess_bytes):
+def test_chess_uses_the_pure_bounded_step_sin(chess_bytes, monkeypatch):
     tape = M.Scene(chess_bytes).lower()
     assert tape.info['sin_ops'] == 256 and tape.info['sin_bounded'] == 256
     L = M.lib()
     L.maray_jit_source.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
-    src = C.c_void_p()
-    assert L.maray_jit_source(C.byref(tape.program), C.byref(src)) == 0
-    text = C.string_at(src).decode()
-    L.maray_free(src)
+
+    def source():
+        src = C.c_void_p()
+        assert L.maray_jit_source(C.byref(tape.program), C.byref(src)) == 0
+        text = C.string_at(src).decode()
+        L.maray_free(src)
+        return text
+    import re
+    text = source()
     assert text.count('mr_stepsin_bounded_m(') == 256 and 'mr_stepsin_fast(' not in text
-    assert text.count('const mr_mask ') > 2500       # half of chess is boolean algebra on lane masks (SGPR pairs)
-    assert text.count('mr_mask bv') > 3600 and ' bool bv' not in text and ' bool v' not in text
+    assert text.count('const mr_mask ') > 2000       # half of chess is boolean algebra on lane masks (SGPR pairs)
+    assert text.count('mr_mask bv') > 2800 and ' bool bv' not in text and ' bool v' not in text
     # the tile with no guard bit set is evaluated four pixels per lane; y values that are booleans are read as masks
     assert 'const mr_d v' in text and text.count('mr_ym(yw, ') >= 64 and 'mr_min(' not in text and 'mr_max(' not in text
-    # a group's guard has no bit of its own: its test is a mask over its members' bits
-    import re
+    # The scene's OR tree of 128 guarded shapes is a reduction: per guard word the set bits of the rectangle at hand are
+    # taken lowest first and reach their shape through a branch table; no bit test of the tree is left in the busy variant,
+    # group guards and "all lanes covered" regions included
+    assert text.count('asm goto(') == 3 and text.count('__builtin_ctzll(mr_rm)') == 3
+    assert len(set(re.findall(r'(mr_rl\d+_0_\d+): \{', text))) == 128 and text.count('mr_racc1_0 |= ') == 128
+    assert not re.findall(r'\(unsigned\)\(?gq\d(?: >> 32\))? & 0x[0-9a-f]+u\)\) != 0u', text)
+    # MARAY_JIT_REDUCE=0: the tree as written -- a group's guard has no bit of its own: its test is a mask over its members' bits
+    monkeypatch.setenv('MARAY_JIT_REDUCE', '0')
+    text = source()
+    assert 'asm goto(' not in text
     assert len(re.findall(r'\(unsigned\)\(?gq\d(?: >> 32\))? & 0x[0-9a-f]+u\)\) != 0u', text)) >= 160
 
 
