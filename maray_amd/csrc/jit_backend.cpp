@@ -134,12 +134,16 @@ struct GuardPlan {
 // proportional to the set bits, not to the tree.  Legal because OR on {+0.0, 1.0} (masks) is associative and commutative,
 // a leaf whose bit is clear is +0.0 over the whole rectangle (that is what its guard says), and an evaluator may ignore
 // any SKIP op: the group guards and the SKIPNZ regions of the tree are not consulted at all (the loop leaves as soon as
-// every lane is covered, which is what the SKIPNZ regions were for).
+// every lane is covered, which is what the SKIPNZ regions were for).  The same for a max tree of f64 values -- every shape
+// with a colour of its own, channel = max_i(shape_i * c_i): NaN-ignoring max with -0 < +0 is associative and commutative
+// bit for bit, a leaf whose bit is clear is +0.0, so the value is the max of the leaves whose bit is set, of the free
+// leaves, and of +0.0 if any bit is clear (the accumulator starts as +0.0 then, else as NaN, max's identity).
 struct RedPlan {
     enum Role : uint8_t { NONE = 0, LEAF_SKIP, LEAF_END, INNER, ROOT, IGNORED_SKIP };
     struct Red {
         uint32_t root = 0;
         std::vector<uint32_t> leaf_skip, leaf_end, leaf_bit;        // guarded leaves: their SKIPZ op, their last op, their guard bit
+        bool boolean = true;                                         // an OR of lane masks; else a max of f64 values
     };
     std::vector<uint8_t> role;          // per op
     std::vector<int32_t> red;           // per op with a role: its reduction
@@ -195,19 +199,20 @@ RedPlan plan_reductions(const uint64_t *ops, uint32_t n, uint32_t n_slots, const
     };
     std::vector<uint8_t> inside_leaf(n, 0);
     for (int32_t R = (int32_t)n - 1; R >= 0; R--) {         // outermost trees first
-        if (MARAY_INS_OP(ops[R]) != MARAY_OP_MAX || !is_bool[R] || rp.role[R] != RedPlan::NONE || inside_leaf[R]) continue;
+        if (MARAY_INS_OP(ops[R]) != MARAY_OP_MAX || rp.role[R] != RedPlan::NONE || inside_leaf[R]) continue;
         std::vector<uint32_t> inner, st{(uint32_t)R};
         RedPlan::Red red;
         red.root = (uint32_t)R;
+        red.boolean = is_bool[R] != 0;
         bool ok = true;
         while (!st.empty() && ok) {
             const uint32_t v = st.back(); st.pop_back();
             inner.push_back(v);
             for (int32_t p : {pa[v], pb[v]}) {
                 if (p < 0) continue;                                               // a literal or a y value: a free leaf
-                if (MARAY_INS_OP(ops[p]) == MARAY_OP_MAX && is_bool[p] && uses[p] == 1 && rp.role[p] == RedPlan::NONE) { st.push_back((uint32_t)p); continue; }
+                if (MARAY_INS_OP(ops[p]) == MARAY_OP_MAX && (is_bool[p] != 0) == red.boolean && uses[p] == 1 && rp.role[p] == RedPlan::NONE) { st.push_back((uint32_t)p); continue; }
                 uint32_t bit = 0;
-                const int32_t s = (is_bool[p] && uses[p] == 1) ? guarded_region((uint32_t)p, &bit) : -1;
+                const int32_t s = ((is_bool[p] || !red.boolean) && uses[p] == 1) ? guarded_region((uint32_t)p, &bit) : -1;
                 if (s < 0) continue;                                               // a free leaf: evaluated where it stands
                 for (uint32_t j = (uint32_t)s; j <= (uint32_t)p && ok; j++) ok = rp.role[j] == RedPlan::NONE && !inside_leaf[j];
                 red.leaf_skip.push_back((uint32_t)s); red.leaf_end.push_back((uint32_t)p); red.leaf_bit.push_back(bit);
@@ -539,15 +544,16 @@ struct Emitter {
             if (role == RedPlan::INNER || role == RedPlan::ROOT) {
                 // an OR of the tree: its operands are parts of the tree (nothing to do) or free leaves (OR-ed in at the root)
                 const int32_t id = rp->red[i];
+                const bool rbool = rp->reds[id].boolean;
                 for (Val *v : {va, vb}) {
                     if (!v || v->kind == REDPART) continue;
-                    const std::string m = v->kind == BOOL ? v->b : "mr_ne0(" + dbl(v, "m", i, v == vb) + ")";
+                    const std::string m = !rbool ? dbl(v, "m", i, v == vb) : v->kind == BOOL ? v->b : "mr_ne0(" + dbl(v, "m", i, v == vb) + ")";
                     if (m != "MR_NONE") red_free[id].push_back(m);
                 }
                 if (role == RedPlan::INNER) {
                     r.kind = REDPART;
                     vals[i] = r;
-                    is_bool_op[i] = 1;
+                    is_bool_op[i] = rbool;
                     acc = (int)i;
                     if (dst != MARAY_DST_NONE) slot[dst] = (int)i;
                     continue;
@@ -558,9 +564,24 @@ struct Emitter {
                 const RedPlan::Red &red = rp->reds[id];
                 const std::string rid = std::to_string(serial) + "_" + std::to_string(id);
                 const std::string racc = "mr_racc" + rid;
-                out += "    mr_mask " + racc + " = MR_NONE";
-                for (const std::string &m : red_free[id]) out += " | " + m;
-                out += ";\n";
+                if (rbool) {
+                    out += "    mr_mask " + racc + " = MR_NONE";
+                    for (const std::string &m : red_free[id]) out += " | " + m;
+                    out += ";\n";
+                } else {
+                    // +0.0 stands for the leaves whose bit is clear; with every bit set there is none: NaN, the identity of max
+                    std::string all;
+                    for (uint32_t wi = 0; wi < guard_words; wi++) {
+                        uint64_t mask = 0;
+                        for (uint32_t b : red.leaf_bit) if (b / 64 == wi) mask |= 1ull << (b % 64);
+                        if (!mask) continue;
+                        char hex[32];
+                        snprintf(hex, sizeof hex, "0x%llxull", (unsigned long long)mask);
+                        all += std::string(all.empty() ? "" : " && ") + "(" + guard_word(wi) + " & " + hex + ") == " + hex;
+                    }
+                    out += "    double " + racc + " = (" + all + ") ? __builtin_nan(\"\") : 0.0;\n";
+                    for (const std::string &m : red_free[id]) out += "    " + racc + " = mr_max(" + racc + ", " + m + ");\n";
+                }
                 for (uint32_t wi = 0; wi < guard_words; wi++) {
                     std::vector<int32_t> leaf_of_bit(64, -1);
                     uint64_t mask = 0;
@@ -571,7 +592,7 @@ struct Emitter {
                     char hex[32];
                     snprintf(hex, sizeof hex, "0x%llxull", (unsigned long long)mask);
                     const std::string w = std::to_string(wi), next = "mr_rn" + rid + "_" + w;
-                    out += "    for (mr_mask mr_rm = " + guard_word(wi) + " & " + hex + "; mr_rm != 0ull && " + racc + " != MR_ALL; ) {\n"
+                    out += "    for (mr_mask mr_rm = " + guard_word(wi) + " & " + hex + "; mr_rm != 0ull" + (rbool ? " && " + racc + " != MR_ALL" : std::string()) + "; ) {\n"
                            "        const unsigned mr_rk = (unsigned)__builtin_ctzll(mr_rm);\n"
                            "        mr_rm &= mr_rm - 1ull;\n"
                            "        asm goto(\"s_getpc_b64 s[20:21]\\n\\ts_add_u32 s20, s20, %0\\n\\ts_addc_u32 s21, s21, 0\\n\\ts_setpc_b64 s[20:21]\"";
@@ -593,7 +614,7 @@ struct Emitter {
                     out += "    " + next + ": ;\n    }\n";
                 }
                 ktab_block.clear();
-                be = racc;
+                if (rbool) be = racc; else e = racc;
             }
             const bool closes = !open.empty() && open.back().end == i && !open.back().leaf;
             if (closes) {
@@ -635,8 +656,9 @@ struct Emitter {
                 if (open.empty() || !open.back().leaf || open.back().end != i) throw Error{MARAY_E_INTERNAL, "reduction leaf out of step"};
                 open.pop_back();
                 const int32_t id = rp->red[i];
-                const std::string m = r.kind == BOOL ? r.b : "mr_ne0(" + dbl(&r, "m", i, 0) + ")";
-                out += "    mr_racc" + std::to_string(serial) + "_" + std::to_string(id) + " |= " + m + ";\n";
+                const std::string ra = "mr_racc" + std::to_string(serial) + "_" + std::to_string(id);
+                if (rp->reds[id].boolean) out += "    " + ra + " |= " + (r.kind == BOOL ? r.b : "mr_ne0(" + dbl(&r, "m", i, 0) + ")") + ";\n";
+                else out += "    " + ra + " = mr_max(" + ra + ", " + dbl(&r, "m", i, 0) + ");\n";
                 red_leaf_text[id][rp->leaf[i]].swap(out);
                 out.swap(out_saved);
                 out_saved.clear();
