@@ -296,6 +296,13 @@ struct Emitter {
 
     // word wi of the guard words of the rectangle at hand: an SGPR pair by name (<= 12 words); beyond, lane wi % 64 of a
     // per-lane value (one v_readlane pair)
+    // many guard words (one per lane): is word wi of the rectangle at hand non-zero at all?  One ballot per pass answers for
+    // every word (mr_gnzp / mr_gnz<j>, jit_source); "" when the words sit in SGPRs and the test is the loop's own
+    std::string guard_word_nonzero(uint32_t wi) const {
+        if (guard_words <= gw_inline_max) return "";
+        if (!gw_lane_base.empty()) return "((mr_gnzp >> " + std::to_string(wi) + "u) & 1ull) != 0ull";
+        return "((mr_gnz" + std::to_string(wi / 64) + " >> " + std::to_string(wi % 64) + "u) & 1ull) != 0ull";
+    }
     std::string guard_word(uint32_t wi) const {
         if (guard_words <= gw_inline_max) return "gq" + std::to_string(wi);
         if (!gw_lane_base.empty()) return "mr_lane64(mr_gt0, " + gw_lane_base + " + " + std::to_string(wi) + "u)";
@@ -592,6 +599,8 @@ struct Emitter {
                     char hex[32];
                     snprintf(hex, sizeof hex, "0x%llxull", (unsigned long long)mask);
                     const std::string w = std::to_string(wi), next = "mr_rn" + rid + "_" + w;
+                    const std::string nz = guard_word_nonzero(wi);
+                    if (!nz.empty()) out += "    if (" + nz + ")\n";
                     out += "    for (mr_mask mr_rm = " + guard_word(wi) + " & " + hex + "; mr_rm != 0ull" + (rbool ? " && " + racc + " != MR_ALL" : std::string()) + "; ) {\n"
                            "        const unsigned mr_rk = (unsigned)__builtin_ctzll(mr_rm);\n"
                            "        mr_rm &= mr_rm - 1ull;\n"
@@ -877,6 +886,8 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
     s += "// generated by libmaray_hip (jit_backend.cpp): ROW section, " + std::to_string(P.n_row_ops) + " ops; y values in " +
          std::to_string(chunks.size()) + " chunks, " + std::to_string(P.n_yvals - n_ynum) + " guards in " + std::to_string(n_gwords) + " words\n";
     s += "#include \"device_math.h\"\n\n";
+    // (constants stay literals here: from a table in constant memory like the PIXEL kernel's, the code is a tenth shorter
+    // and the kernel 0.8 us slower -- the loads' waits sit in the one chain a job is -- and spills to scratch)
     const unsigned row_block = ROW_BLOCK;
     s += "extern \"C\" __global__ void __launch_bounds__(" + std::to_string(row_block) + ") maray_jit_rows(double *__restrict__ yvals, unsigned long long *__restrict__ gbits,\n"
          "                                                                 const MarayTex *__restrict__ tex,\n"
@@ -1022,7 +1033,7 @@ std::string jit_source(const maray_program &P, int min_waves)
     validate_program(P);
     // 6 waves per SIMD, i.e. up to 102 SGPRs (at 8 the compiler gets 76 and spills ~400 of them to VGPR lanes, in the skeleton
     // of bit tests and branches every pass walks; chess needs 38 VGPRs either way and runs 7 waves per SIMD)
-    if (min_waves == 0) min_waves = 6;
+    const int min_waves_arg = min_waves;
     Emitter E(P);
     // Wave-level SKIP ops over fewer than 12 instructions' worth of ops are ignored: a busy tile is bound by the scalar unit
     // (branches, bit tests, mask algebra: 0.59 SALU instructions per cycle and CU against 35 % VALU issue), and a short
@@ -1042,6 +1053,22 @@ std::string jit_source(const maray_program &P, int min_waves)
     const uint32_t sub = 256u / geom.gw;                   // guard rectangles per 256-pixel tile (> 1: their words are taken per pass)
     const std::string tw = std::to_string(sub * n_gwords);  // guard words per tile
     if (n_gwords) { E.guard_first = n_ynum; E.guard_words = n_gwords; E.plan = &plan; E.gw_inline_max = GW_INLINE_MAX; }
+    RedPlan reductions;
+    if (!E.ignore_row_guards) {         // dry run: which ops yield lane masks
+        Emitter D(P);
+        D.ignore_row_guards = true;
+        D.min_region = E.min_region;
+        D.ybool = E.ybool;
+        D.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+        E.bool_hint = D.is_bool_op;
+        // OR trees of guarded shapes: evaluated from their set guard bits (RedPlan).  MARAY_JIT_REDUCE=0: walked as written (ablation)
+        const char *e_ = getenv("MARAY_JIT_REDUCE");
+        if (!(e_ && e_[0] == '0')) reductions = plan_reductions(P.pix_ops, P.n_pix_ops, P.n_pix_slots, D.is_bool_op, n_ynum, plan);
+    }
+    // Occupancy asked of the compiler.  Walking a tree of bit tests needs the SGPRs of 6 waves per SIMD (up to 102; at 8 the
+    // compiler gets 80 and spilled ~400 of them to VGPR lanes, in the skeleton every pass walked); with the tree evaluated as
+    // a reduction chess fits 78 and runs 8 (frame 29.9 -> 29.5 us, sky 12.3 -> 11.5, board 67.1 -> 65.1)
+    if (min_waves_arg == 0) min_waves = reductions.empty() ? 6 : 8;
     const bool defer = may_defer_tiles(P);
     const std::string nw = std::to_string(n_gwords);
     // a strip's guard words: one vector load per wavefront (lane i holds word i), then v_readlane per tile or pass -- one
@@ -1112,18 +1139,6 @@ std::string jit_source(const maray_program &P, int min_waves)
         for (uint32_t j = 0; j < n_gwords; j++)
             s += "    mr_mask gq" + std::to_string(j) + " = mr_lane64(mr_gv, t * " + nw + "u + " + std::to_string(j) + "u);\n";
     if (defer) s += "    ((volatile unsigned *)mr_slow)[mr_wv] = 0u;\n    bool mr_slow_tile = false;\n";
-    RedPlan reductions;
-    if (!E.ignore_row_guards) {         // dry run: which ops yield lane masks
-        Emitter D(P);
-        D.ignore_row_guards = true;
-        D.min_region = E.min_region;
-        D.ybool = E.ybool;
-        D.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
-        E.bool_hint = D.is_bool_op;
-        // OR trees of guarded shapes: evaluated from their set guard bits (RedPlan).  MARAY_JIT_REDUCE=0: walked as written (ablation)
-        const char *e_ = getenv("MARAY_JIT_REDUCE");
-        if (!(e_ && e_[0] == '0')) reductions = plan_reductions(P.pix_ops, P.n_pix_ops, P.n_pix_slots, D.is_bool_op, n_ynum, plan);
-    }
     // what opens a pass of either width: the tables made opaque (LICM would hoist every constant and y value out of the
     // loops and spill them), the pixel coordinates, the outputs
     const std::string opaque =
@@ -1137,7 +1152,9 @@ std::string jit_source(const maray_program &P, int min_waves)
     std::string gq_pass;
     if (n_gwords && !gw_vgpr && sub > 1) {
         gq_pass = "    asm volatile(\"\" : \"+v\"(mr_gt0));\n"
-                  "    const unsigned mr_gsub = " + esub + " * " + nw + "u;           // first word of this pass's rectangle\n";
+                  "    const unsigned mr_gsub = " + esub + " * " + nw + "u;           // first word of this pass's rectangle\n"
+                  "    const unsigned long long mr_gnzp = mr_ballot(mr_gt0 != 0ull) >> mr_gsub;      // which of its words have a bit set\n"
+                  "    (void)mr_gnzp;\n";
         E.gw_lane_base = "mr_gsub";
     } else if (gw_vgpr && sub > 1)
         for (uint32_t j = 0; j < n_gwords; j++) {
@@ -1148,7 +1165,12 @@ std::string jit_source(const maray_program &P, int min_waves)
     else if (gw_vgpr)
         for (uint32_t j = 0; j < n_gwords; j++) gq_pass += "    asm volatile(\"\" : \"+s\"(gq" + std::to_string(j) + "));\n";
     else if (n_gwords)
-        for (uint32_t j = 0; j < (n_gwords + 63) / 64; j++) gq_pass += "    asm volatile(\"\" : \"+v\"(mr_gt" + std::to_string(j) + "));\n";
+        for (uint32_t j = 0; j < (n_gwords + 63) / 64; j++) {
+            const std::string k = std::to_string(j);
+            gq_pass += "    asm volatile(\"\" : \"+v\"(mr_gt" + k + "));\n"
+                       "    const unsigned long long mr_gnz" + k + " = mr_ballot(mr_gt" + k + " != 0ull);      // which of the tile's words have a bit set\n"
+                       "    (void)mr_gnz" + k + ";\n";
+        }
     const std::string wide_open =
         "    {\n" + opaque + (sub > 1 ? std::string() : gq_pass) +
         "    const unsigned xa = x0 + mr_xl;                                        // this lane's first pixel\n"
@@ -1629,10 +1651,10 @@ std::shared_ptr<const JitCode> build_code(const maray_program &prog, CodeKey &k)
             have_pix = rp == HELPER_OK; have_rows = rr == HELPER_OK;
         }
     }
-    // Occupancy: the highest of 6 / 4 / 2 waves per SIMD (<= 80 / 128 / 256 VGPRs) whose build needs no scratch:
-    // spilled VGPRs are HBM traffic.
-    const int ladder[] = {6, 4, 2};
-    for (int i = 0; i < 3; i++) {
+    // Occupancy: the generator's own choice (8 or 6 waves per SIMD, jit_source), then 6 / 4 / 2 (<= 80 / 128 / 256 VGPRs)
+    // until a build needs no scratch: spilled VGPRs are HBM traffic.
+    const int ladder[] = {0, 6, 4, 2};
+    for (int i = 0; i < 4; i++) {
         if (!(i == 0 && have_pix)) jit_compile(i == 0 ? k.src_pix : jit_source(prog, ladder[i]), c->pix, log);
         c->waves = ladder[i];
         if (code_meta_uint(c->pix, ".private_segment_fixed_size") <= 0) break;
