@@ -26,6 +26,15 @@ MARAY_DEV double mr_mask_f64(mr_mask m, unsigned on, unsigned off)
     return __builtin_bit_cast(double, (unsigned long long)hi << 32);
 }
 MARAY_DEV double mr_pos(mr_mask m) { return mr_mask_f64(m, 0x3ff00000u, 0u); }               /* +1.0 : +0.0 */
+// v on the lanes of m, +0.0 on the others (two v_cndmask_b32 on the mask)
+MARAY_DEV double mr_sel0(mr_mask m, double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    unsigned lo, hi;
+    asm("s_mov_b64 vcc, %4\n\tv_cndmask_b32_e32 %0, 0, %2, vcc\n\tv_cndmask_b32_e32 %1, 0, %3, vcc"
+        : "=&v"(lo), "=v"(hi) : "v"((unsigned)u), "v"((unsigned)(u >> 32)), "s"(m) : "vcc");
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 MARAY_DEV double mr_neg01(mr_mask m) { return mr_mask_f64(m, 0xbff00000u, 0x80000000u); }    /* -1.0 : -0.0 */
 
 // Neg Abs Recip Sqrt: IEEE-754 exact (:640-643).  1.0/a and sqrt lower to the
@@ -151,6 +160,7 @@ MARAY_DEV mr_m operator|(const mr_m &x, const mr_m &y) { return mr_m(x.a | y.a, 
 MARAY_DEV mr_m operator~(const mr_m &x) { return mr_m(~x.a, ~x.b, ~x.c, ~x.d); }
 MARAY_DEV bool mr_any(const mr_m &m) { return (m.a | m.b | m.c | m.d) != MR_NONE; }
 MARAY_DEV mr_d mr_pos(const mr_m &m) { return mr_d(mr_pos(m.a), mr_pos(m.b), mr_pos(m.c), mr_pos(m.d)); }
+MARAY_DEV mr_d mr_sel0(const mr_m &m, const mr_d &v) { return mr_d(mr_sel0(m.a, v.a), mr_sel0(m.b, v.b), mr_sel0(m.c, v.c), mr_sel0(m.d, v.d)); }
 MARAY_DEV mr_d mr_neg01(const mr_m &m) { return mr_d(mr_neg01(m.a), mr_neg01(m.b), mr_neg01(m.c), mr_neg01(m.d)); }
 MARAY_DEV mr_m mr_ge0(const mr_d &v) { return mr_m(mr_ge0(v.a), mr_ge0(v.b), mr_ge0(v.c), mr_ge0(v.d)); }
 MARAY_DEV mr_m mr_ne0(const mr_d &v) { return mr_m(mr_ne0(v.a), mr_ne0(v.b), mr_ne0(v.c), mr_ne0(v.d)); }

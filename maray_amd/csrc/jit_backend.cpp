@@ -350,7 +350,9 @@ struct Emitter {
             }
         };
         // the double form of a value, materialising it once if needed
-        struct Open { uint32_t end; bool as_bool; bool nz; uint32_t id; bool leaf; };      // leaf: the block of a reduction's leaf (no variable, no else)
+        // leaf: the block of a reduction's leaf (no variable, no else).  mask: the lanes on which what the region computes can
+        // matter -- a wave-level region of booleans computes q of n = p AND q (p OR q): where p is 0 (1), n does not depend on q
+        struct Open { uint32_t end; bool as_bool; bool nz; uint32_t id; bool leaf; std::string mask; };
         std::vector<Open> open;     // SKIPZ / SKIPNZ regions being emitted, innermost last
         uint32_t next_scope = 1;
         auto dbl = [&](Val *v, const char *hint, uint32_t i, int which) -> std::string {
@@ -385,7 +387,7 @@ struct Emitter {
             if (role == RedPlan::IGNORED_SKIP) continue;            // legal: an evaluator may ignore any SKIP op
             if (role == RedPlan::LEAF_SKIP) {
                 out_saved.swap(out);                                // (out_saved was empty: leaves do not nest)
-                open.push_back(Open{i + aux, true, false, next_scope++, true});
+                open.push_back(Open{i + aux, true, false, next_scope++, true, std::string()});
                 ktab_block.clear();
                 continue;
             }
@@ -465,7 +467,8 @@ struct Emitter {
                 // instruction fetch).  A wave-level region of the PIXEL section sits inside a shape whose guard let the wavefront
                 // in, and is entered nine times in ten (18 of 20 per pass): likely (board crop 82.3 -> 81.6 us).
                 out += "    if (__builtin_expect(" + cond + (pixel && !row_guard ? ", 1)) {\n" : ", 0)) {\n");
-                open.push_back(Open{end, typed_bool, nz, next_scope++, false});
+                open.push_back(Open{end, typed_bool, nz, next_scope++, false,
+                                    (!row_guard && as_bool && va->kind == BOOL) ? (nz ? "~" + va->b : va->b) : std::string()});
                 ktab_block.clear();
                 continue;
             }
@@ -504,6 +507,16 @@ struct Emitter {
             auto m_not = [](const std::string &a) -> std::string {
                 return a == "MR_NONE" ? "MR_ALL" : (a == "MR_ALL" ? "MR_NONE" : "~" + a);
             };
+            // The argument of a Sin that may send its tile to the interpreter (huge, inf, NaN, or too close to a multiple of
+            // pi/2 for the fast sign): on the lanes where the enclosing regions' result does not depend on what they compute,
+            // 0.0 instead -- a texture coordinate runs wild OUTSIDE its shape, where the shape's mask discards the pattern
+            // anyway, and without this nearly every tile of a scene of textured shapes was re-rendered by the interpreter
+            // (1,000 triangles: 2.2 ms of the frame's 2.4).
+            auto quiet_arg = [&](const std::string &x) -> std::string {
+                std::string m;
+                for (const Open &o : open) if (!o.mask.empty()) m += (m.empty() ? "" : " & ") + o.mask;
+                return m.empty() ? x : "mr_sel0(" + m + ", " + x + ")";
+            };
             if (forced[i]) be = forced[i] == 2 ? "MR_ALL" : "MR_NONE";     // exactly +0.0 / 1.0: a boolean whatever the op
             else if (role == RedPlan::INNER || role == RedPlan::ROOT) ;     // an OR of a reduction: below
             else
@@ -516,7 +529,7 @@ struct Emitter {
             case MARAY_OP_STEP: be = "mr_ge0(" + dbl(va, "m", i, 0) + ")"; break;
             case MARAY_OP_STEPSIN:
                 if (aux & MARAY_AUX_SIN_BOUNDED) be = "mr_stepsin_bounded_m(" + dbl(va, "m", i, 0) + ")";
-                else e = pixel ? "mr_stepsin_fast(" + dbl(va, "m", i, 0) + ", &mr_defer)" : "mr_stepsin(" + dbl(va, "m", i, 0) + ")";
+                else e = pixel ? "mr_stepsin_fast(" + quiet_arg(dbl(va, "m", i, 0)) + ", &mr_defer)" : "mr_stepsin(" + dbl(va, "m", i, 0) + ")";
                 break;
             case MARAY_OP_ADD:
                 // 1.0 + (-(b)) = NOT b
@@ -540,7 +553,7 @@ struct Emitter {
             case MARAY_OP_RECIP: e = "mr_recip(" + dbl(va, "m", i, 0) + ")"; break;
             case MARAY_OP_SQRT: e = "mr_sqrt(" + dbl(va, "m", i, 0) + ")"; break;
             case MARAY_OP_SIN:
-                e = (aux & MARAY_AUX_SIN_BOUNDED) ? "mr_sin_bounded(" + dbl(va, "m", i, 0) + ")" : "mr_sin(" + dbl(va, "m", i, 0) + ")";
+                e = (aux & MARAY_AUX_SIN_BOUNDED) ? "mr_sin_bounded(" + dbl(va, "m", i, 0) + ")" : "mr_sin(" + (pixel ? quiet_arg(dbl(va, "m", i, 0)) : dbl(va, "m", i, 0)) + ")";
                 break;
             case MARAY_OP_EXP: e = "mr_exp(" + dbl(va, "m", i, 0) + ")"; break;
             case MARAY_OP_LN: e = "mr_ln(" + dbl(va, "m", i, 0) + ")"; break;

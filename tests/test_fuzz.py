@@ -100,3 +100,39 @@ def test_polygon_soups_gpu_vs_oracle():
             ctx.close()
             assert same_f64(got64, want64), (seed, b)
             assert np.array_equal(got8, want8), (seed, b)
+
+
+@pytest.mark.gpu
+def test_a_thousand_triangles_gpu_vs_oracle():
+    """More than 768 guarded shapes (12 guard words): a rectangle's words stay one per lane, the scene's OR tree is a
+    reduction with a branch table per word, words without a bit are skipped by one ballot per pass.  The triangles carry
+    patterns whose Sin arguments run wild outside the triangle: the lanes there are fed 0.0 (jit_backend.cpp, quiet_arg),
+    else nearly every tile would be re-rendered by the interpreter.  Every pixel of the specialised kernels against the
+    scalar-cache interpreter (u8 and f64 planes), bands against the oracle; the same scene with the tree walked as
+    written (MARAY_JIT_REDUCE=0) gives the same raster."""
+    import os
+    from fuzz_scenes import polygon_soup
+    w, h = 1536, 640
+    data = encode((w, h), polygon_soup(21, 1000, w, h, mixed=False))
+    tape = M.Scene(data).lower()
+    assert tape.info['n_yvals'] > 3000 and tape.info['sin_bounded'] < tape.info['sin_ops']
+    ref = M.Context(tape, backend=M.BACKEND_TAPE_SMEM)
+    want8, want64 = ref.render_rows(w, h, 0, h)
+    ref.close()
+    for mode in (None, '0'):
+        if mode is None:
+            os.environ.pop('MARAY_JIT_REDUCE', None)
+        else:
+            os.environ['MARAY_JIT_REDUCE'] = mode
+        try:
+            ctx = M.Context(tape, backend=M.BACKEND_JIT)
+            got8, got64 = ctx.render_rows(w, h, 0, h)
+            ctx.close()
+        finally:
+            os.environ.pop('MARAY_JIT_REDUCE', None)
+        assert np.array_equal(got8, want8), mode
+        assert same_f64(got64, want64), mode
+    o = OScene(data)
+    for y0, y1 in ((0, 4), (317, 323), (636, 640)):
+        o8, o64 = o.render_rows(w, h, y0, y1)
+        assert np.array_equal(want8[y0:y1], o8) and same_f64(want64[y0:y1], o64), y0

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/run_crop.py SCENE CROP [REPS] — launches of the specialised kernels over one 4096 x 4096 crop, for rocprofv3.
 
-SCENE: chess (config 3) | allops (config 3b) | radial (config 2).  CROP (chess only): frame | sky | board — the
+SCENE: chess (config 3) | allops (config 3b) | radial (config 2) | soupN (N random textured triangles).  CROP (chess only): frame | sky | board — the
 frame itself, or 4096^2 pixels of nothing but sky / nothing but board rows (chess stretched 16x vertically).
 Backend from MARAY_BENCH_BACKEND (jit | tape-smem | tape; default jit).  Prints the HIP-event time per launch of the
 pixel kernel."""
@@ -27,6 +27,11 @@ if scene_name == 'chess':
     s.rescale(4, sy)
     h = 1024 * sy
     y0 = {'frame': 0, 'sky': 0, 'board': 8192}[crop]
+elif scene_name.startswith('soup'):        # soup1000, soup300 ...: tests/fuzz_scenes.py polygon_soup, one tree for the three channels
+    import fuzz_scenes
+    from marayb import encode
+    s = M.Scene(encode((4096, 4096), fuzz_scenes.polygon_soup(1, int(scene_name[4:]), 4096, 4096, mixed=False)))
+    h, y0 = 4096, 0
 else:
     import scenes
     from marayb import encode
