@@ -121,6 +121,7 @@ def lib():
         'maray_gen_cache_clear': (None, []),
         'maray_png_write': (C.c_int, [C.c_char_p, vp, u32, u32]),
         'maray_png_read': (C.c_int, [C.c_char_p, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]),
+        'maray_image_read': (C.c_int, [C.c_char_p, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]),
         'maray_free': (None, [vp]),
     }
     for name, (res, args) in sig.items():
@@ -421,9 +422,14 @@ def png_write(path, rgb8):
     _check(lib().maray_png_write(os.fsencode(path), a.ctypes.data, a.shape[1], a.shape[0]))
 
 
-def png_read(path):
+def image_read(path):
+    """`image::open(path).to_rgb8()`: a texture file in any format the library reads -> HxWx3 uint8."""
+    return png_read(path, _fn='maray_image_read')
+
+
+def png_read(path, _fn='maray_png_read'):
     p, w, h = C.c_void_p(), C.c_uint32(), C.c_uint32()
-    _check(lib().maray_png_read(os.fsencode(path), C.byref(p), C.byref(w), C.byref(h)))
+    _check(getattr(lib(), _fn)(os.fsencode(path), C.byref(p), C.byref(w), C.byref(h)))
     try:
         a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(h.value, w.value, 3)).copy()
     finally:

@@ -52,6 +52,8 @@ void host_unregister(void *p);                  // throws Error
 bool host_range_is_pinned(const void *p, size_t n);
 
 void set_last_error(const std::string &m);   // thread-local message behind maray_last_error()
+int read_whole_file(const char *path, std::vector<uint8_t> &b);                                             // png.cpp; MARAY_E_IO + message on failure
+int png_decode(const std::vector<uint8_t> &b, uint8_t **rgb8_out, uint32_t *w_out, uint32_t *h_out);       // png.cpp
 int hip_device_count();
 Backend *make_tape_backend(int device, const maray_program &prog, const maray_texture *tex, uint32_t n_tex, bool lds_variant);
 Backend *make_jit_backend(int device, const maray_program &prog, const maray_texture *tex, uint32_t n_tex);

@@ -18,7 +18,7 @@ static void usage()
             "  -c, --cpus <cpus>            Number of CPU cores (accepted, unused)\n"
             "  -i, --input <input>          Input file `*.maray`\n"
             "  -o, --output <output>        Output file `*.png`\n"
-            "  -t, --textures <textures>... Texture file `*.png`\n"
+            "  -t, --textures <textures>... Texture files (PNG, BMP, PNM, TGA, QOI, farbfeld)\n"
             "      --gpus <n>               Number of MI355X devices (default: all)\n"
             "      --backend <b>            auto | jit | tape | tape-smem (default: auto)\n");
 }
@@ -56,7 +56,7 @@ int main(int argc, char **argv)
     std::vector<uint8_t *> rasters;
     for (const std::string &t : textures) {
         uint8_t *rgb = nullptr; uint32_t w = 0, h = 0;
-        if (maray_png_read(t.c_str(), &rgb, &w, &h)) { fprintf(stderr, "Error: %s: %s\n", t.c_str(), maray_last_error()); return 1; }
+        if (maray_image_read(t.c_str(), &rgb, &w, &h)) { fprintf(stderr, "Error: %s: %s\n", t.c_str(), maray_last_error()); return 1; }
         rasters.push_back(rgb);
         tex.push_back(maray_texture{rgb, w, h});
     }

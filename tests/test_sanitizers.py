@@ -86,3 +86,55 @@ def test_png_reader_with_crafted_headers_under_asan_ubsan(tmp_path):
                UBSAN_OPTIONS='print_stacktrace=1')
     out = subprocess.run([exe] + paths, capture_output=True, text=True, env=env)
     assert out.returncode == 0 and 'png ok' in out.stdout, out.stdout[-2500:] + out.stderr[-3000:]
+
+
+def test_image_readers_with_crafted_headers_under_asan_ubsan(tmp_path):
+    """maray_image_read (BMP, PNM, TGA, QOI, farbfeld; tests/test_image_formats.py has the decodings) on headers that lie:
+    sizes whose products overflow, pixel data shorter than promised, run-length packets past the end, palette indices past
+    the palette, offsets past the file."""
+    import struct
+
+    import numpy as np
+    from PIL import Image
+    csrc = os.path.join(ROOT, 'maray_amd', 'csrc')
+    exe = str(tmp_path / 'image_asan')
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-g', '-fsanitize=address,undefined', '-fno-sanitize-recover=all',
+                           '-I' + csrc, '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'native', 'image_asan.cpp'),
+                           os.path.join(csrc, 'png.cpp'), os.path.join(csrc, 'image.cpp'), '-o', exe, '-lz'])
+    rng = np.random.default_rng(3)
+    im = Image.fromarray(rng.integers(0, 256, (9, 13, 3), dtype=np.uint8))
+    paths = []
+    for name in ('good.bmp', 'good.ppm', 'good.tga', 'good.png'):
+        p = str(tmp_path / name)
+        im.save(p)
+        paths.append(p)
+    im.convert('P', palette=Image.ADAPTIVE, colors=8).save(str(tmp_path / 'good_pal.bmp'))
+    im.save(str(tmp_path / 'good_rle.tga'), compression='tga_rle')
+    paths += [str(tmp_path / 'good_pal.bmp'), str(tmp_path / 'good_rle.tga')]
+
+    def bmp(w, h, bpp, off=54, body=b'', hdr=40, ncol=0):
+        return b'BM' + struct.pack('<IHHI', 0, 0, 0, off) + struct.pack('<IiiHHIIiiII', hdr, w, h, 1, bpp, 0, 0, 0, 0, ncol, 0) + body
+    good_bmp = open(paths[0], 'rb').read()
+    files = {
+        'bmp_huge.bmp': bmp(1 << 20, 1 << 20, 24), 'bmp_wrap.bmp': bmp(0x7FFFFFFF, 3, 32), 'bmp_short.bmp': bmp(64, 64, 24, body=bytes(100)),
+        'bmp_off.bmp': bmp(4, 4, 24, off=0xFFFFFFF0, body=bytes(64)), 'bmp_neg.bmp': bmp(-4, 4, 24, body=bytes(64)),
+        'bmp_minh.bmp': bmp(4, -(1 << 31), 24, body=bytes(64)), 'good_pal3.bmp': bmp(4, 4, 8, off=54 + 12, body=bytes(12) + bytes([0, 1, 2, 200] * 4), ncol=3),      # an index past the palette reads as black
+        'bmp_hdr.bmp': bmp(4, 4, 24, hdr=0xFFFFFF00, body=bytes(64)), 'bmp_trunc.bmp': good_bmp[:70],
+        'pnm_huge.ppm': b'P6 1048576 1048576 255\n', 'pnm_short.ppm': b'P6 40 40 255\n' + bytes(100), 'pnm_big.ppm': b'P6 99999999999 2 255\n',
+        'pnm_max.ppm': b'P6 2 2 70000\n' + bytes(24), 'pnm_plain.ppm': b'P3 4 4 255 1 2 3', 'pnm_bits.pbm': b'P4 17 3\n' + bytes(5),
+        'tga_short.tga': bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 64, 0, 64, 0, 24, 0]) + bytes(50),
+        'tga_rle.tga': bytes([0, 0, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 64, 0, 64, 0, 24, 0, 0xFF, 1, 2]),
+        'good_map.tga': bytes([0, 1, 1, 0, 0, 2, 0, 24, 0, 0, 0, 0, 4, 0, 4, 0, 8, 0]) + bytes(6) + bytes([9] * 16),      # indices past the colour map read as black
+        'tga_id.tga': bytes([255, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 0, 4, 0, 24, 0]) + bytes(20),
+        'qoi_short.qoi': b'qoif' + struct.pack('>IIBB', 64, 64, 3, 0) + bytes([0xFE, 1, 2]) + bytes(8),
+        'qoi_huge.qoi': b'qoif' + struct.pack('>IIBB', 0xFFFFFFFF, 0xFFFFFFFF, 4, 0) + bytes(16),
+        'ff_short.ff': b'farbfeld' + struct.pack('>II', 100, 100) + bytes(64), 'ff_huge.ff': b'farbfeld' + struct.pack('>II', 0xFFFFFFFF, 2),
+    }
+    for name, data in files.items():
+        p = str(tmp_path / name)
+        open(p, 'wb').write(data)
+        paths.append(p)
+    env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=1:allocator_may_return_null=1:max_allocation_size_mb=4096',
+               UBSAN_OPTIONS='print_stacktrace=1')
+    out = subprocess.run([exe] + paths, capture_output=True, text=True, env=env)
+    assert out.returncode == 0 and 'images ok' in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
