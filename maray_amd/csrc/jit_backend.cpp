@@ -860,8 +860,6 @@ GuardGeom jit_guard_geom(const maray_program &P)
     return g;
 }
 
-uint32_t jit_guard_rows(const maray_program &P) { return jit_guard_geom(P).gh; }
-
 static const unsigned ROW_BLOCK = 256;          // threads per block of the ROW kernel (64 ... 1024 move a chess frame by less than a microsecond)
 
 // Source of the ROW kernel, maray_jit_rows: one wavefront per block, blockIdx.y picks the job.
@@ -1402,16 +1400,17 @@ void mkdirs(const std::string &d)
         if (i == d.size() || d[i] == '/') (void)mkdir(d.substr(0, i).c_str(), 0777);
 }
 
-const uint32_t CACHE_MAGIC = 0x6f63726du;    // "mrco"
+const uint32_t CACHE_MAGIC = 0x3263726du;    // "mrc2": 9 header words (guard geometry in the header)
 
 bool cache_read(const std::string &path, JitCode &c)
 {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
-    uint32_t hdr[6];
-    bool ok = fread(hdr, 4, 6, f) == 6 && hdr[0] == CACHE_MAGIC && hdr[4] < (1u << 30) && hdr[5] < (1u << 30);
+    uint32_t hdr[9];
+    bool ok = fread(hdr, 4, 9, f) == 9 && hdr[0] == CACHE_MAGIC && hdr[4] < (1u << 30) && hdr[5] < (1u << 30);
     if (ok) {
         c.n_row_chunks = hdr[1]; c.n_gjobs = hdr[2]; c.waves = (int)hdr[3];
+        c.n_gwords = hdr[6]; c.guard_w = hdr[7]; c.guard_h = hdr[8];
         c.pix.resize(hdr[4]); c.rows.resize(hdr[5]);
         ok = fread(c.pix.data(), 1, c.pix.size(), f) == c.pix.size() && fread(c.rows.data(), 1, c.rows.size(), f) == c.rows.size();
         uint64_t sum = 0;
@@ -1427,9 +1426,10 @@ void cache_write(const std::string &dir, const std::string &path, const JitCode 
     const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
     FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return;                                       // a read-only or missing cache directory is not an error
-    const uint32_t hdr[6] = {CACHE_MAGIC, c.n_row_chunks, c.n_gjobs, (uint32_t)c.waves, (uint32_t)c.pix.size(), (uint32_t)c.rows.size()};
+    const uint32_t hdr[9] = {CACHE_MAGIC, c.n_row_chunks, c.n_gjobs, (uint32_t)c.waves, (uint32_t)c.pix.size(), (uint32_t)c.rows.size(),
+                             c.n_gwords, c.guard_w, c.guard_h};
     const uint64_t sum = fnv1a(c.rows.data(), c.rows.size(), fnv1a(c.pix.data(), c.pix.size(), 0xcbf29ce484222325ull));
-    const bool ok = fwrite(hdr, 4, 6, f) == 6 && fwrite(c.pix.data(), 1, c.pix.size(), f) == c.pix.size() &&
+    const bool ok = fwrite(hdr, 4, 9, f) == 9 && fwrite(c.pix.data(), 1, c.pix.size(), f) == c.pix.size() &&
                     fwrite(c.rows.data(), 1, c.rows.size(), f) == c.rows.size() && fwrite(&sum, 8, 1, f) == 1;
     if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());      // rename: readers never see half a file
 }
@@ -1674,6 +1674,10 @@ std::shared_ptr<const JitCode> build_code(const maray_program &prog, CodeKey &k)
     }
     if (prog.n_row_ops && !have_rows) jit_compile(k.src_rows, c->rows, log);
     c->n_row_chunks = k.n_row_chunks; c->n_gjobs = k.n_gjobs;
+    if (prog.n_row_ops) {          // (the guard plan is a walk over the ROW tape: once here, not in every context's creation)
+        const GuardGeom geom = jit_guard_geom(prog);
+        c->n_gwords = jit_guard_words(prog); c->guard_w = geom.gw; c->guard_h = geom.gh;
+    }
     if (!path.empty()) cache_write(dir, path, *c);
     return c;
 }
@@ -1785,11 +1789,23 @@ struct JitBackend final : Backend {
             t_last = now;
         };
         HIP_TRY(hipSetDevice(dev));
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, dev));
-        if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
-            throw Error{MARAY_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only"};
-        n_cu = (uint32_t)std::max(1, prop.multiProcessorCount);
+        // (hipGetDeviceProperties costs ~5 ms a call: asked once per device and process)
+        static std::mutex prop_mutex;
+        static std::map<int, std::pair<std::string, int>> props;
+        std::pair<std::string, int> info;
+        {
+            std::lock_guard<std::mutex> lk(prop_mutex);
+            auto it = props.find(dev);
+            if (it == props.end()) {
+                hipDeviceProp_t prop;
+                HIP_TRY(hipGetDeviceProperties(&prop, dev));
+                it = props.emplace(dev, std::make_pair(std::string(prop.gcnArchName), prop.multiProcessorCount)).first;
+            }
+            info = it->second;
+        }
+        if (info.first.rfind("gfx950", 0) != 0)
+            throw Error{MARAY_E_NO_DEVICE, "device is " + info.first + ", this library is built for gfx950 only"};
+        n_cu = (uint32_t)std::max(1, info.second);
         has_sin = may_defer_tiles(prog);
         wide_all = jit_wide_general(prog);
         if (const char *e_ = getenv("MARAY_JIT_TILES")) if (atoi(e_) > 0) k_tiles = (unsigned)atoi(e_);
@@ -1806,10 +1822,10 @@ struct JitBackend final : Backend {
         if (prog.n_row_ops) {
             HIP_TRY(hipModuleLoadData(&mod_rows, code->rows.data()));
             HIP_TRY(hipModuleGetFunction(&f_rows, mod_rows, "maray_jit_rows"));
-            n_gwords = jit_guard_words(prog);
+            n_gwords = code->n_gwords;
             if (n_gwords) HIP_TRY(hipModuleGetFunction(&f_order, mod_rows, "maray_jit_order"));
-            guard_rows = jit_guard_rows(prog);
-            guard_sub = 256u / jit_guard_geom(prog).gw;
+            guard_rows = code->guard_h;
+            guard_sub = 256u / code->guard_w;
             lap("load ROW module");
 
         }
