@@ -143,6 +143,10 @@ struct RedPlan {
     struct Red {
         uint32_t root = 0;
         std::vector<uint32_t> leaf_skip, leaf_end, leaf_bit;        // guarded leaves: their SKIPZ op, their last op, their guard bit
+        // per leaf: the y values that are boolean FACTORS of it (the leaf is an AND tree and they are among its operands: a
+        // shape's horizontal edge).  0 on this row => the leaf is 0 on this row, whatever its rectangle's guard bit says: one
+        // scalar test ahead of the leaf's body
+        std::vector<std::vector<uint32_t>> leaf_yfactors;
         bool boolean = true;                                         // an OR of lane masks; else a max of f64 values
     };
     std::vector<uint8_t> role;          // per op
@@ -155,7 +159,7 @@ struct RedPlan {
 // is_bool: per op, the emitter's own typing (a dry run).  guard g of a SKIPZ on y value guard_first + g has bit gp.pos[g]
 // (or is derived: no bit).  A tree qualifies when it has at least `min_leaves` guarded leaves.
 RedPlan plan_reductions(const uint64_t *ops, uint32_t n, uint32_t n_slots, const std::vector<uint8_t> &is_bool, uint32_t guard_first,
-                        const GuardPlan &gp, uint32_t min_leaves = 4)
+                        const GuardPlan &gp, const std::vector<uint8_t> &ybool, uint32_t min_leaves = 4)
 {
     RedPlan rp;
     rp.role.assign(n, RedPlan::NONE); rp.red.assign(n, -1); rp.leaf.assign(n, -1);
@@ -239,8 +243,24 @@ RedPlan plan_reductions(const uint64_t *ops, uint32_t n, uint32_t n_slots, const
             rp.role[v] = v == (uint32_t)R ? RedPlan::ROOT : RedPlan::INNER; rp.red[v] = id;
             for (uint32_t s : skips_ending[v]) { rp.role[s] = RedPlan::IGNORED_SKIP; rp.red[s] = id; }
         }
+        red.leaf_yfactors.resize(red.leaf_end.size());
         for (size_t k = 0; k < red.leaf_end.size(); k++) {
             const uint32_t s = red.leaf_skip[k], e = red.leaf_end[k];
+            if (red.boolean) {          // the AND tree under the leaf's last op, through ANDs with one reader
+                std::vector<uint32_t> andst{e};
+                while (!andst.empty()) {
+                    const uint32_t v = andst.back(); andst.pop_back();
+                    const uint32_t op = MARAY_INS_OP(ops[v]);
+                    if (!(op == MARAY_OP_MUL || op == MARAY_OP_MIN) || !is_bool[v]) continue;
+                    const uint32_t refs[2] = {MARAY_INS_A(ops[v]), MARAY_INS_B(ops[v])};
+                    const int32_t prods[2] = {pa[v], pb[v]};
+                    for (int q = 0; q < 2; q++) {
+                        if (MARAY_REF_KIND(refs[q]) == MARAY_K_YVAL && MARAY_REF_INDEX(refs[q]) < ybool.size() && ybool[MARAY_REF_INDEX(refs[q])])
+                            red.leaf_yfactors[k].push_back(MARAY_REF_INDEX(refs[q]));
+                        else if (prods[q] >= (int32_t)s && uses[prods[q]] == 1) andst.push_back((uint32_t)prods[q]);       // (a factor may guard a wave-level region as well)
+                    }
+                }
+            }
             for (uint32_t j = s; j <= e; j++) inside_leaf[j] = 1;
             // regions that end at the leaf's last op and start before its guard's SKIPZ would enclose it: ignored as well
             for (uint32_t q : skips_ending[e]) if (q < s) { rp.role[q] = RedPlan::IGNORED_SKIP; rp.red[q] = id; }
@@ -631,7 +651,11 @@ struct Emitter {
                            "        goto " + next + ";              // (not reached: the asm always jumps; `unreachable` here crashes the back end)\n";
                     for (int b = 0; b <= top; b++) {
                         if (leaf_of_bit[b] < 0) continue;
-                        out += "    mr_rl" + rid + "_" + std::to_string(leaf_of_bit[b]) + ": {\n" + red_leaf_text[id][leaf_of_bit[b]] + "    } goto " + next + ";\n";
+                        std::string yf;              // the leaf's y factors: all must hold on this row
+                        for (uint32_t yk : red.leaf_yfactors[leaf_of_bit[b]]) yf += (yf.empty() ? "" : " & ") + std::string("mr_ym(yw, ") + std::to_string(yk) + "u)";
+                        out += "    mr_rl" + rid + "_" + std::to_string(leaf_of_bit[b]) + ": {\n" +
+                               (yf.empty() ? std::string() : "    if ((" + yf + ") == MR_NONE) goto " + next + ";      // not on this row (frame 29.5 -> 29.0 us)\n") +
+                               red_leaf_text[id][leaf_of_bit[b]] + "    } goto " + next + ";\n";
                     }
                     out += "    " + next + ": ;\n    }\n";
                 }
@@ -1006,14 +1030,14 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
 
 // The general section four pixels per lane: only a short program without guards whose ops are single instructions (no libm
 // bodies, no gathers).
-bool jit_wide_general(const maray_program &P)
+bool jit_wide_general(const maray_program &P, uint32_t n_gwords)        // n_gwords = jit_guard_words(P) (a walk over the ROW tape: the caller has it)
 {
     bool heavy = false;
     for (uint32_t i = 0; i < P.n_pix_ops; i++) {
         const uint32_t op = MARAY_INS_OP(P.pix_ops[i]);
         heavy |= op == MARAY_OP_SIN || op == MARAY_OP_EXP || op == MARAY_OP_LN || op == MARAY_OP_STEPSIN || op == MARAY_OP_APP;
     }
-    return jit_guard_words(P) == 0 && !heavy && P.n_pix_slots <= 6 && P.n_pix_ops <= 256;
+    return n_gwords == 0 && !heavy && P.n_pix_slots <= 6 && P.n_pix_ops <= 256;
 }
 
 // Source of the PIXEL kernel, maray_jit_pixels.  A wavefront owns a strip of `tiles` consecutive 256-pixel tiles of one
@@ -1074,7 +1098,7 @@ std::string jit_source(const maray_program &P, int min_waves)
         E.bool_hint = D.is_bool_op;
         // OR trees of guarded shapes: evaluated from their set guard bits (RedPlan).  MARAY_JIT_REDUCE=0: walked as written (ablation)
         const char *e_ = getenv("MARAY_JIT_REDUCE");
-        if (!(e_ && e_[0] == '0')) reductions = plan_reductions(P.pix_ops, P.n_pix_ops, P.n_pix_slots, D.is_bool_op, n_ynum, plan);
+        if (!(e_ && e_[0] == '0')) reductions = plan_reductions(P.pix_ops, P.n_pix_ops, P.n_pix_slots, D.is_bool_op, n_ynum, plan, E.ybool);
     }
     // Occupancy asked of the compiler.  Walking a tree of bit tests needs the SGPRs of 6 waves per SIMD (up to 102; at 8 the
     // compiler gets 80 and spilled ~400 of them to VGPR lanes, in the skeleton every pass walked); with the tree evaluated as
@@ -1085,7 +1109,7 @@ std::string jit_source(const maray_program &P, int min_waves)
     // a strip's guard words: one vector load per wavefront (lane i holds word i), then v_readlane per tile or pass -- one
     // memory latency per strip instead of one per tile
     const bool gw_vgpr = n_gwords && n_gwords <= GW_INLINE_MAX;
-    const bool wide_general = jit_wide_general(P);
+    const bool wide_general = jit_wide_general(P, n_gwords);
     const std::string esub = "(e >> " + std::to_string(sub == 4 ? 0 : 1) + "u)";       // rectangle of pass e inside its tile
     s += "// generated by libmaray_hip (jit_backend.cpp) from a v" + std::to_string(P.version) + " tape: PIXEL section, " +
          std::to_string(P.n_pix_ops) + " ops; general variant " + (wide_general ? "four pixels per lane" : "one pixel per lane, four passes per tile") + "\n"
@@ -1807,7 +1831,7 @@ struct JitBackend final : Backend {
             throw Error{MARAY_E_NO_DEVICE, "device is " + info.first + ", this library is built for gfx950 only"};
         n_cu = (uint32_t)std::max(1, info.second);
         has_sin = may_defer_tiles(prog);
-        wide_all = jit_wide_general(prog);
+        // (set below, from the code object's header: the guard plan is not recomputed per context)
         if (const char *e_ = getenv("MARAY_JIT_TILES")) if (atoi(e_) > 0) k_tiles = (unsigned)atoi(e_);
         lap("device");
         code = jit_code_for(prog);                       // built by the first context of the process, or read from the cache
@@ -1816,6 +1840,7 @@ struct JitBackend final : Backend {
         HIP_TRY(hipModuleGetFunction(&f_pix, mod, "maray_jit_pixels"));
         lap("load PIXEL module");
         n_row_chunks = code->n_row_chunks; n_gjobs = code->n_gjobs;
+        wide_all = jit_wide_general(prog, code->n_gwords);
         if (has_sin) slow = make_tape_backend(dev, prog, tex, n_tex, false);     // drains the tiles the pixel kernel defers; other programs never defer
         P = prog;
         P.consts = nullptr; P.row_ops = nullptr; P.pix_ops = nullptr;
