@@ -272,6 +272,10 @@ RedPlan plan_reductions(const uint64_t *ops, uint32_t n, uint32_t n_slots, const
     return rp;
 }
 
+// f64::max / f64::min on constants, as lower.cpp folds them and v_max_f64 / v_min_f64 compute them (NaN-ignoring, -0 < +0)
+inline double fold_max(double a, double b) { if (a != a) return b; if (b != b) return a; if (a == b) return std::signbit(a) ? b : a; return a > b ? a : b; }
+inline double fold_min(double a, double b) { if (a != a) return b; if (b != b) return a; if (a == b) return std::signbit(a) ? a : b; return a < b ? a : b; }
+
 struct Emitter {
     enum Kind { DBL, BOOL, NEGBOOL, REDPART };   // NEGBOOL: value is -(b) in {-0.0, -1.0}, b = the named mask; REDPART: part of a guarded OR-reduction (RedPlan): no value of its own
     struct Val {
@@ -279,6 +283,8 @@ struct Emitter {
         std::string d;   // name / literal of the double, empty until materialised
         std::string b;   // name / literal of the lane mask (BOOL, NEGBOOL)
         uint32_t d_scope = 0;   // the region (C++ block) the materialised double was declared in; 0 = the kernel's own block
+        bool cst = false;       // a known constant (a literal of the tape, MR_NONE / MR_ALL as numbers, or arithmetic on such): cval
+        double cval = 0.0;
     };
     const maray_program &P;
     std::string out;
@@ -348,6 +354,7 @@ struct Emitter {
             case MARAY_K_CONST: {
                 const double c = P.consts[idx];
                 t.d = lit(c);
+                t.cst = true; t.cval = c;
                 uint64_t bits; memcpy(&bits, &c, 8);
                 if (ktab && !inline_f64(bits)) {
                     auto it = ktab_block.find(bits);
@@ -537,7 +544,39 @@ struct Emitter {
                 for (const Open &o : open) if (!o.mask.empty()) m += (m.empty() ? "" : " & ") + o.mask;
                 return m.empty() ? x : "mr_sel0(" + m + ", " + x + ")";
             };
-            if (forced[i]) be = forced[i] == 2 ? "MR_ALL" : "MR_NONE";     // exactly +0.0 / 1.0: a boolean whatever the op
+            // Arithmetic on known constants is done here (the lowering folded what it could see; what is left appears when a
+            // variant makes guarded regions literals: a tile without a guard bit paints `0.0 * 255`, and as long as that was a
+            // multiply the sky paid a constant's load, its wait and twelve conversions per lane for a colour known beforehand).
+            // + * max min neg on doubles are IEEE-exact on the host (lower.cpp folds with the same functions).
+            bool folded = false;
+            double fold_val = 0.0;
+            auto known = [](const Val *v, double *c) -> bool {
+                if (!v) return false;
+                if (v->cst) { *c = v->cval; return true; }
+                if ((v->kind == BOOL || v->kind == NEGBOOL) && (v->b == "MR_NONE" || v->b == "MR_ALL")) {
+                    *c = v->b == "MR_ALL" ? 1.0 : 0.0;
+                    if (v->kind == NEGBOOL) *c = -*c;
+                    return true;
+                }
+                return false;
+            };
+            {
+                double ca = 0.0, cb = 0.0;
+                const bool ka = known(va, &ca), kb = known(vb, &cb);
+                if (!forced[i] && role != RedPlan::INNER && role != RedPlan::ROOT) {
+                    if (ka && kb && (op == MARAY_OP_ADD || op == MARAY_OP_MUL || op == MARAY_OP_MIN || op == MARAY_OP_MAX)) {
+                        folded = true;
+                        fold_val = op == MARAY_OP_ADD ? ca + cb : op == MARAY_OP_MUL ? ca * cb : op == MARAY_OP_MAX ? fold_max(ca, cb) : fold_min(ca, cb);
+                    } else if (ka && op == MARAY_OP_NEG) { folded = true; fold_val = -ca; }
+                }
+            }
+            if (folded) {
+                uint64_t fb; memcpy(&fb, &fold_val, 8);
+                if (fb == 0) be = "MR_NONE";                                   // +0.0 and 1.0 stay what constants of the tape are: literal masks
+                else if (fb == 0x3ff0000000000000ull) be = "MR_ALL";
+                else e = lit(fold_val);
+            }
+            else if (forced[i]) be = forced[i] == 2 ? "MR_ALL" : "MR_NONE";     // exactly +0.0 / 1.0: a boolean whatever the op
             else if (role == RedPlan::INNER || role == RedPlan::ROOT) ;     // an OR of a reduction: below
             else
             switch (op) {
@@ -693,6 +732,8 @@ struct Emitter {
             } else if (!be.empty()) {
                 out += "    const " + tm + " b" + self + " = " + be + ";\n";
                 r.kind = BOOL; r.b = "b" + self;
+            } else if (!e.empty() && folded) {
+                r.kind = DBL; r.d = e; r.cst = true; r.cval = fold_val;      // a literal: no statement
             } else if (!e.empty()) {
                 out += "    const " + td + " " + self + " = " + e + ";\n";
                 r.kind = DBL; r.d = self;

@@ -46,8 +46,9 @@ def test_chess_uses_the_pure_bounded_step_sin(chess_bytes, monkeypatch):
     assert text.count('mr_stepsin_bounded_m(') == 256 and 'mr_stepsin_fast(' not in text
     assert text.count('const mr_mask ') > 2000       # half of chess is boolean algebra on lane masks (SGPR pairs)
     assert text.count('mr_mask bv') > 2800 and ' bool bv' not in text and ' bool v' not in text
-    # the tile with no guard bit set is evaluated four pixels per lane; y values that are booleans are read as masks
-    assert 'const mr_d v' in text and text.count('mr_ym(yw, ') >= 64 and 'mr_min(' not in text and 'mr_max(' not in text
+    # the tile with no guard bit set is four pixels per lane of a colour the emitter folded (0.0 * 255: no load, no
+    # multiply); y values that are booleans are read as masks
+    assert 'mr_d o0 = 0.0' in text and '* mr_kc[0]' not in text.split('mr_d o0 = 0.0')[1].split('mr_u3')[0] and text.count('mr_ym(yw, ') >= 64 and 'mr_min(' not in text and 'mr_max(' not in text
     # The scene's OR tree of 128 guarded shapes is a reduction: per guard word the set bits of the rectangle at hand are
     # taken lowest first and reach their shape through a branch table; no bit test of the tree is left in the busy variant,
     # group guards and "all lanes covered" regions included
