@@ -4,7 +4,7 @@
 CONFIG = NAME[:VAR=VALUE[,VAR=VALUE...]] (environment knobs of DESIGN.md 7.1, read at context creation / launch).
 Per config: pixel-kernel time (HIP events, pixel kernel only) of the 4096^2 frame, of 4096^2 pixels of sky and of
 board (chess stretched 16x vertically), the whole step (ROW + PIXEL kernels, outputs in HBM) and the build time;
-the frame is checked against the golden hash."""
+the frame is checked against the golden hash.  EXP_LIBM=1: configs 3b and 2 @4096^2 as well."""
 import ctypes as C
 import hashlib
 import json
@@ -55,6 +55,20 @@ def run(name, env):
             out['sky_us'] = round(ctx.time_rows(4096, 16384, 0, 4096, d_rgb8=dbuf.value, reps=30) * 1e3, 2)
             out['board_us'] = round(ctx.time_rows(4096, 16384, 8192, 12288, d_rgb8=dbuf.value, reps=30) * 1e3, 2)
             ctx.close()
+        if os.environ.get('EXP_LIBM'):          # config 3b (sin / exp / ln / sqrt) and config 2 (sqrt) @4096^2, checked against the interpreter
+            sys.path.insert(0, os.path.join(ROOT, 'tests'))
+            import scenes
+            from marayb import encode
+            for nm, col in (('allops', scenes.all_ops(4096, 4096)), ('radial', scenes.radial_gradient())):
+                t = M.Scene(encode((4096, 4096), col)).lower()
+                ctx = M.Context(t, backend=M.BACKEND_JIT)
+                ref = M.Context(t, backend=M.BACKEND_TAPE_SMEM)
+                a8, a64 = ctx.render_rows(4096, 4096, 1000, 1256, want_f64=True)
+                b8, b64 = ref.render_rows(4096, 4096, 1000, 1256, want_f64=True)
+                out[nm + '_parity'] = bool(np.array_equal(a8, b8) and np.array_equal(a64.view(np.uint64), b64.view(np.uint64)))
+                out[nm + '_us'] = round(ctx.time_rows(4096, 4096, 0, 4096, d_rgb8=dbuf.value, reps=20) * 1e3, 2)
+                ctx.close()
+                ref.close()
     except Exception as e:      # noqa: BLE001
         out['error'] = str(e)[-400:]
     for k in env:
