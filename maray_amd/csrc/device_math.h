@@ -87,6 +87,24 @@ MARAY_DEV mr_mask mr_ge0(double a) { return mr_ballot(a >= 0.0); }       // Step
 MARAY_DEV mr_mask mr_ne0(double a) { return mr_ballot(a != 0.0); }
 MARAY_DEV mr_mask mr_ne1(double a) { return mr_ballot(a != 1.0); }
 MARAY_DEV mr_mask mr_stepsin_bounded_m(double a) { return mr_ballot(maray_libm_step_sin_bounded(a) != 0.0); }
+// The same with the six constants of the argument reduction read from k[0..5] (scalar loads from the kernel's constant
+// table: one cache line) instead of being 64-bit literals: gfx950 has no 64-bit literal operand, and a literal costs two
+// s_mov on the scalar unit each time a leaf is entered -- 12 of a chess leaf's ~50 scalar instructions.
+// k = {2/pi, 1.5 * 2^52, mp1, mp2, pp3, pp4} (maray_libm.h MR_HPINV .. MR_PP4): the operations are those of
+// maray_libm_step_sin_bounded, operand for operand.
+MARAY_DEV mr_mask mr_stepsin_bounded_mk(double x, const __attribute__((address_space(4))) double *k)
+{
+    const double hpinv = k[0], toint = k[1], mp1 = k[2], mp2 = k[3], pp3 = k[4], pp4 = k[5];
+    const double t = mr_fma(x, hpinv, toint);
+    const double xn = t - toint;
+    const unsigned n = (unsigned)mr_bits(t);
+    const double y = mr_fma(-xn, mp2, mr_fma(-xn, mp1, x));
+    const double t2 = mr_fma(-xn, pp3, y);
+    const double a = mr_fma(-xn, pp4, t2);
+    unsigned s_ = (n & 1u) ? 0u : (unsigned)(mr_bits(a) >> 32);
+    s_ ^= n << 30;
+    return mr_ballot((int)s_ >= 0);
+}
 MARAY_DEV bool mr_any(mr_mask m) { return m != MR_NONE; }
 // a y value known to be +0.0 or 1.0 (the same on every lane) as a lane mask: one scalar load and compare on its high word
 // (the high word is 0 or 0x3ff00000: bit 20 spread over a mask by integer arithmetic.  Written as a select, the back end may

@@ -301,6 +301,7 @@ struct Emitter {
     bool assume_guards_zero = false;             // PIXEL: emit the variant for a tile none of whose guard bits is set
     bool out_guard_bits = false;                 // ROW-section OUT of a guard (index >= guard_first): OR its bit into `gacc`
     bool ktab = false;
+    int sin_k = -1;                    // >= 0: the bounded Step(Sin) reads its reduction constants from mr_kc[sin_k .. sin_k + 5]
     uint32_t min_region = 0;                    // PIXEL: wave-level SKIP ops over fewer ops than this are ignored
     uint32_t min_region_row = 0;                // ROW: the same (a wavefront's lanes are 64 rows, or the 64 rectangles of a band of rows)
     // y values that are booleans (exactly +0.0 or 1.0 on every row: a Step of y-only arguments and what AND / OR / NOT make
@@ -587,7 +588,8 @@ struct Emitter {
                 break;
             case MARAY_OP_STEP: be = "mr_ge0(" + dbl(va, "m", i, 0) + ")"; break;
             case MARAY_OP_STEPSIN:
-                if (aux & MARAY_AUX_SIN_BOUNDED) be = "mr_stepsin_bounded_m(" + dbl(va, "m", i, 0) + ")";
+                if ((aux & MARAY_AUX_SIN_BOUNDED) && sin_k >= 0 && td == "double") be = "mr_stepsin_bounded_mk(" + dbl(va, "m", i, 0) + ", mr_kc + " + std::to_string(sin_k) + ")";
+                else if (aux & MARAY_AUX_SIN_BOUNDED) be = "mr_stepsin_bounded_m(" + dbl(va, "m", i, 0) + ")";
                 else e = pixel ? "mr_stepsin_fast(" + quiet_arg(dbl(va, "m", i, 0)) + ", &mr_defer)" : "mr_stepsin(" + dbl(va, "m", i, 0) + ")";
                 break;
             case MARAY_OP_ADD:
@@ -1120,6 +1122,13 @@ std::string jit_source(const maray_program &P, int min_waves)
     if (const char *e_ = getenv("MARAY_JIT_MIN_REGION")) E.min_region = (uint32_t)atoi(e_);
     E.ybool = jit_bool_yvals(P);
     E.ktab = true;
+    for (uint32_t i = 0; i < P.n_pix_ops && E.sin_k < 0; i++)
+        if (MARAY_INS_OP(P.pix_ops[i]) == MARAY_OP_STEPSIN && (MARAY_INS_AUX(P.pix_ops[i]) & MARAY_AUX_SIN_BOUNDED)) {
+            // the first cache line of the table: what every leaf with a texture reads
+            static const double sin_k[8] = {0x1.45f306dc9c883p-1, 0x1.8p52, 0x1.921fb58000000p+0, -0x1.dde973c000000p-27, -0x1.cb3b398000000p-55, -0x1.d747f23e32ed7p-83, 0.0, 0.0};
+            E.sin_k = 0;
+            E.ktab_vals.assign(sin_k, sin_k + 8);
+        }
     std::string &s = E.out;
     const uint32_t n_ynum = numeric_yvals(P);
     const uint32_t n_gwords = jit_guard_words(P);
@@ -1367,7 +1376,7 @@ std::string jit_source(const maray_program &P, int min_waves)
     {
         std::string tab = store_run;
         if (!E.ktab_vals.empty()) {
-            tab += "__constant__ double mr_kc_tab[" + std::to_string(E.ktab_vals.size()) + "] = {";
+            tab += "__constant__ __attribute__((aligned(64))) double mr_kc_tab[" + std::to_string(E.ktab_vals.size()) + "] = {";
             for (size_t j = 0; j < E.ktab_vals.size(); j++) { tab += (j % 6 ? " " : "\n    "); tab += lit(E.ktab_vals[j]); tab += ","; }
             tab += "\n};\n";
         }

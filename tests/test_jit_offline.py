@@ -43,7 +43,7 @@ def test_chess_uses_the_pure_bounded_step_sin(chess_bytes, monkeypatch):
         return text
     import re
     text = source()
-    assert text.count('mr_stepsin_bounded_m(') == 256 and 'mr_stepsin_fast(' not in text
+    assert text.count('mr_stepsin_bounded_mk(') == 256 and 'mr_stepsin_fast(' not in text
     assert text.count('const mr_mask ') > 2000       # half of chess is boolean algebra on lane masks (SGPR pairs)
     assert text.count('mr_mask bv') > 2800 and ' bool bv' not in text and ' bool v' not in text
     # the tile with no guard bit set is four pixels per lane of a colour the emitter folded (0.0 * 255: no load, no
