@@ -105,6 +105,26 @@ MARAY_DEV mr_mask mr_stepsin_bounded_mk(double x, const __attribute__((address_s
     s_ ^= n << 30;
     return mr_ballot((int)s_ >= 0);
 }
+// maray_libm_step_sin_fast the same way (k[6] = 2^-70, the bound below which the sign of the reduced argument is not
+// taken for the sign of the sine)
+MARAY_DEV double mr_stepsin_fast_k(double x, float *defer, const __attribute__((address_space(4))) double *k)
+{
+    const double hpinv = k[0], toint = k[1], mp1 = k[2], mp2 = k[3], pp3 = k[4], pp4 = k[5], tiny = k[6];
+    const unsigned kx = (unsigned)(mr_bits(x) >> 32) & 0x7fffffffu;
+    const double t = mr_fma(x, hpinv, toint);
+    const double xn = t - toint;
+    const unsigned n = (unsigned)mr_bits(t);
+    const double y = mr_fma(-xn, mp2, mr_fma(-xn, mp1, x));
+    const double t2 = mr_fma(-xn, pp3, y);
+    const double a = mr_fma(-xn, pp4, t2);
+    const bool odd = (n & 1u) != 0;
+    const bool neg_red = (odd ? false : (mr_bits(a) >> 63) != 0) != ((n & 2u) != 0);
+    const bool small = kx < 0x400368fdu;
+    const bool undecided = (kx >= 0x419921FBu) | (!small & !odd & !(mr_fabs(a) >= tiny));
+    *defer += undecided ? 1.0f : 0.0f;
+    const bool one = small ? (x >= 0.0) : !neg_red;
+    return one ? 1.0 : 0.0;
+}
 MARAY_DEV bool mr_any(mr_mask m) { return m != MR_NONE; }
 // a y value known to be +0.0 or 1.0 (the same on every lane) as a lane mask: one scalar load and compare on its high word
 // (the high word is 0 or 0x3ff00000: bit 20 spread over a mask by integer arithmetic.  Written as a select, the back end may

@@ -590,6 +590,7 @@ struct Emitter {
             case MARAY_OP_STEPSIN:
                 if ((aux & MARAY_AUX_SIN_BOUNDED) && sin_k >= 0 && td == "double") be = "mr_stepsin_bounded_mk(" + dbl(va, "m", i, 0) + ", mr_kc + " + std::to_string(sin_k) + ")";
                 else if (aux & MARAY_AUX_SIN_BOUNDED) be = "mr_stepsin_bounded_m(" + dbl(va, "m", i, 0) + ")";
+                else if (pixel && sin_k >= 0 && td == "double") e = "mr_stepsin_fast_k(" + quiet_arg(dbl(va, "m", i, 0)) + ", &mr_defer, mr_kc + " + std::to_string(sin_k) + ")";
                 else e = pixel ? "mr_stepsin_fast(" + quiet_arg(dbl(va, "m", i, 0)) + ", &mr_defer)" : "mr_stepsin(" + dbl(va, "m", i, 0) + ")";
                 break;
             case MARAY_OP_ADD:
@@ -1123,9 +1124,9 @@ std::string jit_source(const maray_program &P, int min_waves)
     E.ybool = jit_bool_yvals(P);
     E.ktab = true;
     for (uint32_t i = 0; i < P.n_pix_ops && E.sin_k < 0; i++)
-        if (MARAY_INS_OP(P.pix_ops[i]) == MARAY_OP_STEPSIN && (MARAY_INS_AUX(P.pix_ops[i]) & MARAY_AUX_SIN_BOUNDED)) {
+        if (MARAY_INS_OP(P.pix_ops[i]) == MARAY_OP_STEPSIN) {
             // the first cache line of the table: what every leaf with a texture reads
-            static const double sin_k[8] = {0x1.45f306dc9c883p-1, 0x1.8p52, 0x1.921fb58000000p+0, -0x1.dde973c000000p-27, -0x1.cb3b398000000p-55, -0x1.d747f23e32ed7p-83, 0.0, 0.0};
+            static const double sin_k[8] = {0x1.45f306dc9c883p-1, 0x1.8p52, 0x1.921fb58000000p+0, -0x1.dde973c000000p-27, -0x1.cb3b398000000p-55, -0x1.d747f23e32ed7p-83, 0x1p-70, 0.0};
             E.sin_k = 0;
             E.ktab_vals.assign(sin_k, sin_k + 8);
         }
