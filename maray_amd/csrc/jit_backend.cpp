@@ -963,7 +963,9 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
     if (n_chunks_out) *n_chunks_out = (uint32_t)chunks.size();
     std::string &s = E.out;
     s += "// generated by libmaray_hip (jit_backend.cpp): ROW section, " + std::to_string(P.n_row_ops) + " ops; y values in " +
-         std::to_string(chunks.size()) + " chunks, " + std::to_string(P.n_yvals - n_ynum) + " guards in " + std::to_string(n_gwords) + " words\n";
+         std::to_string(chunks.size()) + " chunks, " + std::to_string(P.n_yvals - n_ynum) + " guards in " + std::to_string(n_gwords) + " words,\n"
+         "// each bounded over rectangles of " + std::to_string(geom.gw) + " pixels x " + std::to_string(geom.gh) + " rows (the height is a launch parameter, and part of the code key through this line:\n"
+         "// a cached code object carries its geometry)\n";
     s += "#include \"device_math.h\"\n\n";
     // (constants stay literals here: from a table in constant memory like the PIXEL kernel's, the code is a tenth shorter
     // and the kernel 0.8 us slower -- the loads' waits sit in the one chain a job is -- and spills to scratch)

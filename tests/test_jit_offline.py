@@ -130,8 +130,13 @@ def test_code_key_is_remembered_under_the_programs_name(chess_bytes, tmp_path, m
     monkeypatch.setenv('MARAY_JIT_GUARD_W', '256')                      # changes the generated kernels
     other = tape.jit_code_key
     assert other != key and len(os.listdir(tmp_path)) == 3
-    monkeypatch.delenv('MARAY_JIT_TILES')
     monkeypatch.delenv('MARAY_JIT_GUARD_W')
+    # the rectangle's height is a launch parameter that a code object carries with it (the cache file's header): it names
+    # the object too, or a cached default would be launched with its own height whatever the knob says
+    monkeypatch.setenv('MARAY_JIT_GUARD_H', '8')
+    assert tape.jit_code_key not in (key, other)
+    monkeypatch.delenv('MARAY_JIT_GUARD_H')
+    monkeypatch.delenv('MARAY_JIT_TILES')
     # a name file that is not a key is ignored and rewritten
     open(tmp_path / names[0], 'w').write('not a key')
     import subprocess
