@@ -48,25 +48,33 @@ def test_random_scenes_lowering_vs_oracle():
     assert done >= 50
 
 
+def _jit_contexts(cases):
+    """The specialised contexts of several scenes, built side by side: a build is two compiler processes per scene
+    (maray_jitc), the calling thread only waits for them.  cases: (tape, textures) pairs."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(8) as pool:
+        return list(pool.map(lambda c: M.Context(c[0], textures=c[1], backend=M.BACKEND_JIT), cases))
+
+
 @pytest.mark.gpu
 def test_random_scenes_gpu_vs_oracle():
     tex = scenes.textures(scale=64)
-    done = 0
+    cases = []
     for seed in list(range(100, 140)) + [1007, 1145]:       # the last two: a lane mask that is EXEC itself (tools/gpu_fuzz.py found them)
         n_tex = 2 if seed % 3 == 0 else 0
         data, tape = lowered(seed, n_tex)
-        if tape is None:
-            continue
-        t = tex if n_tex else None
+        if tape is not None:
+            cases.append((seed, data, tape, tex if n_tex else None))
+    assert len(cases) >= 30
+    jit = _jit_contexts([(tape, t) for _, _, tape, t in cases])
+    for (seed, data, tape, t), jctx in zip(cases, jit):
         want8, want64 = OScene(data).render_rows(W, H, 0, H, t)
         for b in (M.BACKEND_JIT, M.BACKEND_TAPE, M.BACKEND_TAPE_SMEM):
-            ctx = M.Context(tape, textures=t, backend=b)
+            ctx = jctx if b == M.BACKEND_JIT else M.Context(tape, textures=t, backend=b)
             got8, got64 = ctx.render_rows(W, H, 0, H)
             ctx.close()
             assert same_f64(got64, want64), (seed, b)
             assert np.array_equal(got8, want8), (seed, b)
-        done += 1
-    assert done >= 30
 
 
 def test_polygon_soups_lowering_vs_oracle():
@@ -90,12 +98,15 @@ def test_polygon_soups_lowering_vs_oracle():
 def test_polygon_soups_gpu_vs_oracle():
     from fuzz_scenes import polygon_soup
     w, h = 1024, 200
+    cases = []
     for seed in range(10, 16):
         data = encode((w, h), polygon_soup(seed, 70, w, h, mixed=(True, False, 'colours')[seed % 3]))
-        tape = M.Scene(data).lower()
+        cases.append((seed, data, M.Scene(data).lower()))
+    jit = _jit_contexts([(tape, None) for _, _, tape in cases])
+    for (seed, data, tape), jctx in zip(cases, jit):
         want8, want64 = OScene(data).render_rows(w, h, 0, h)
         for b in (M.BACKEND_JIT, M.BACKEND_TAPE, M.BACKEND_TAPE_SMEM):
-            ctx = M.Context(tape, backend=b)
+            ctx = jctx if b == M.BACKEND_JIT else M.Context(tape, backend=b)
             got8, got64 = ctx.render_rows(w, h, 0, h)
             ctx.close()
             assert same_f64(got64, want64), (seed, b)
