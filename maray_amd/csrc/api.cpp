@@ -391,7 +391,7 @@ int maray_hip_ctx_create(int device, const maray_program *prog, const maray_text
             bool want_jit = prog->n_pix_ops <= 25000;
             if (want_jit && opts && opts->hint_mpixels) {
                 // cached code objects cost a context ~0.02 s more than the interpreter's (two module loads; the key comes from the
-                // program's name, jit_backend.cpp) -- 0.2 s when the process has to generate the sources for the key first
+                // program's name, jit_build.cpp) -- 0.2 s when the process has to generate the sources for the key first
                 const double build_s = jit_code_is_cached(*prog) ? 0.02 : 0.5 + 4.0e-4 * prog->n_pix_ops + 2.4e-4 * prog->n_row_ops;
                 const bool guarded = prog->n_yvals > numeric_yvals(*prog);
                 const double interp_s = (double)opts->hint_mpixels * prog->n_pix_ops * 4.4e-6 * (guarded ? 0.05 : 1.0);

@@ -60,7 +60,7 @@ Backend *make_jit_backend(int device, const maray_program &prog, const maray_tex
 std::string jit_source(const maray_program &prog, int min_waves = 0);   // PIXEL kernel source (__launch_bounds__(256, min_waves); 0 = the layout's default); throws Error
 std::string jit_source_rows(const maray_program &prog, uint32_t *n_chunks_out = nullptr, uint32_t *n_gjobs_out = nullptr);   // ROW kernel source (blockIdx.y = chunk)
 void jit_compile(const std::string &src, std::vector<char> &code, std::string &log);     // hiprtc, gfx950; throws Error
-// The two code objects of a program (jit_backend.cpp): built once per process, kept on disk under MARAY_CACHE_DIR.
+// The two code objects of a program (jit_build.cpp): built once per process, kept on disk under MARAY_CACHE_DIR.
 struct JitCode {
     std::vector<char> pix, rows;        // maray_jit_pixels; maray_jit_rows + maray_jit_order (empty without a ROW section)
     uint32_t n_row_chunks = 1, n_gjobs = 0;

@@ -803,7 +803,7 @@ struct TapeBackend final : Backend {
         // guard bits per rectangle: only with this back-end's own ROW pass (a caller's y-value table carries the guards
         // as y values bounded over the row), and only if a group of rows never straddles two row blocks
         const bool bits = tile_guards && !ext_yvals;
-        // The rectangle a guard is bounded over: 64 pixels x 32 rows, like the specialised path's (jit_backend.cpp,
+        // The rectangle a guard is bounded over: 64 pixels x 32 rows, like the specialised path's (jit_source.cpp,
         // jit_guard_geom: as many rectangles as 256 x 8, closer to a shape's outline for a wavefront of 64 pixels);
         // fewer rows when a group would straddle two row blocks.  MARAY_TAPE_GUARD_W / _H (read at context creation): measurement knobs.
         uint32_t want_rows = k_guard_h, guard_sub = k_guard_sub;

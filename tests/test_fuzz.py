@@ -117,7 +117,7 @@ def test_polygon_soups_gpu_vs_oracle():
 def test_a_thousand_triangles_gpu_vs_oracle():
     """More than 768 guarded shapes (12 guard words): a rectangle's words stay one per lane, the scene's OR tree is a
     reduction with a branch table per word, words without a bit are skipped by one ballot per pass.  The triangles carry
-    patterns whose Sin arguments run wild outside the triangle: the lanes there are fed 0.0 (jit_backend.cpp, quiet_arg),
+    patterns whose Sin arguments run wild outside the triangle: the lanes there are fed 0.0 (jit_emit.hpp, quiet_arg),
     else nearly every tile would be re-rendered by the interpreter.  Every pixel of the specialised kernels against the
     scalar-cache interpreter (u8 and f64 planes), bands against the oracle; the same scene with the tree walked as
     written (MARAY_JIT_REDUCE=0) gives the same raster."""

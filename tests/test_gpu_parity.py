@@ -206,7 +206,7 @@ print('config 4 ok')
 
 def test_chess_16384_in_one_launch_equals_the_interpreter_on_every_byte(chess_bytes):
     """The launch `bench.py --scaling strong` times: the whole 16384^2 frame in ONE launch takes four tiles per wavefront
-    (jit_backend.cpp, launch()), a shape the 24 MiB host tiles of the test above never take.  Every byte against the
+    (jit_backend.cpp: launch()), a shape the 24 MiB host tiles of the test above never take.  Every byte against the
     interpreter's, on the device (PyTorch buffers: a process of its own), and rank 3 of 8's interleaved share against the
     rows of the whole frame."""
     import subprocess
