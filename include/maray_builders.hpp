@@ -15,6 +15,7 @@
 //   Expr::subst2 / scale     src/lib.rs:709-735, 804-806
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <cstdio>
@@ -35,6 +36,7 @@ struct Node;
 using Expr = std::shared_ptr<const Node>;
 using Point2 = std::array<Expr, 2>;
 using Point3 = std::array<Expr, 3>;
+using Point4 = std::array<Expr, 4>;
 using Color = std::array<Expr, 3>;
 
 struct Node {
@@ -57,6 +59,15 @@ inline Expr app(uint32_t id, Expr a, Expr b) { return mk(App, a, b, id); }
 inline Expr x() { return mk(X); }
 inline Expr y() { return mk(Y); }
 inline Expr var_id(uint64_t id) { return mk(Var, nullptr, nullptr, id); }
+// var (src/lib.rs:845-850): the id is the name's hash -- Rust's `str::hash` feeds the bytes and a 0xff terminator to
+// fnv::FnvHasher (FNV-1a, 64 bit)
+inline Expr var(const std::string &name)
+{
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (unsigned char c : name) { h ^= c; h *= 0x100000001b3ull; }
+    h ^= 0xffu; h *= 0x100000001b3ull;
+    return var_id(h);
+}
 inline Expr tau() { return mk(Tau); }
 inline Expr e() { return mk(E); }
 inline Expr nat(uint64_t a) { return mk(Nat, nullptr, nullptr, a); }
@@ -143,6 +154,11 @@ inline Point2 p2_lerp(Point2 a, Point2 b, Expr t) { return {lerp(a[0], b[0], t),
 inline Point2 p2_pos(Expr cond, Point2 a, Point2 b) { return p2_lerp(b, a, step_pos(cond)); }
 inline Point2 p2_circle(Expr ang) { return {cos(ang), sin(ang)}; }
 inline Point2 p2_qbez(Point2 a, Point2 b, Point2 c, Expr t) { return p2_lerp(p2_lerp(a, b, t), p2_lerp(b, c, t), t); }
+inline Point2 p2_cbez(Point2 a, Point2 b, Point2 c, Point2 d, Expr t) { return p2_lerp(p2_qbez(a, b, c, t), p2_qbez(b, c, d, t), t); }   // :1061-1065
+inline Point2 p2_spiral(Expr ang) { return p2_scale(p2_circle(ang), rad_to_unit(ang)); }                                               // :1035-1037
+inline Point4 p4_same(Expr v) { return {v, v, v, v}; }                                                                                   // :1141-1151
+inline Point2 p4_xy(const Point4 &p) { return {p[0], p[1]}; }
+inline Point2 p4_zw(const Point4 &p) { return {p[2], p[3]}; }
 
 // ---- quads, triangles, uv (src/lib.rs:1078-1131) ------------------------------------------------
 inline Point3 to_barycentric(const std::array<Point2, 3> &tri, Point2 p)
@@ -227,6 +243,59 @@ inline Expr subst2(const Expr &ex, const Point2 &p)
 }
 inline Expr scale(const Expr &ex, Point2 s) { return subst2(ex, p2_div({x(), y()}, s)); }     // :804-806
 inline Expr translate(const Expr &ex, Point2 off) { return subst2(ex, p2_sub({x(), y()}, off)); }   // :799-801
+inline Expr scale_at(const Expr &ex, Point2 off, Point2 s) { return translate(scale(translate(ex, p2_neg(off)), s), off); }   // :809-811
+inline Expr rotate(const Expr &ex, Expr rad)   // :814-821
+{
+    const Expr sn = sin(rad), cs = cos(rad);
+    const Point2 id = {x(), y()};
+    return subst2(ex, {p2_dot({cs, neg(sn)}, id), p2_dot({sn, cs}, id)});
+}
+inline Expr rotate_at(const Expr &ex, Point2 off, Expr rad) { return translate(rotate(translate(ex, p2_neg(off)), rad), off); }   // :824-826
+inline Point2 p2_subst(const Point2 &p, const Point2 &off) { return {subst2(p[0], off), subst2(p[1], off)}; }                    // :1067-1070
+// from_barycentric (:1127-1138)
+inline Point2 from_barycentric(const std::array<Point2, 3> &tri, const Point3 &l)
+{
+    return {add(add(mul(l[0], tri[0][0]), mul(l[1], tri[1][0])), mul(l[2], tri[2][0])),
+            add(add(mul(l[0], tri[0][1]), mul(l[1], tri[1][1])), mul(l[2], tri[2][1]))};
+}
+
+// Expr::var_range (:738-764): the half-open range of variable ids an expression mentions or defines; empty = {0, 0}
+inline std::array<uint64_t, 2> var_range_union(std::array<uint64_t, 2> a, std::array<uint64_t, 2> b)   // :830-834
+{
+    if (a[1] - a[0] == 0) return b;
+    if (b[1] - b[0] == 0) return a;
+    return {std::min(a[0], b[0]), std::max(a[1], b[1])};
+}
+inline std::array<uint64_t, 2> var_range(const Expr &ex)
+{
+    switch (ex->tag) {
+    case Arc: case Decor: return var_range(ex->a);
+    case X: case Y: case Tau: case E: case Nat: case Encoded: return {0, 0};
+    case Var: return {ex->u, ex->u + 1};
+    case Let: {
+        std::array<uint64_t, 2> r = var_range(ex->a);            // (the body)
+        for (const auto &v : ex->vars) { r = var_range_union(r, {v.first, v.first + 1}); r = var_range_union(r, var_range(v.second)); }
+        return r;
+    }
+    default: return ex->b ? var_range_union(var_range(ex->a), var_range(ex->b)) : var_range(ex->a);
+    }
+}
+// Expr::var_offset (:767-796): every variable id, used or defined, moved by off
+inline Expr var_offset(const Expr &ex, int64_t off)
+{
+    switch (ex->tag) {
+    case Arc: return var_offset(ex->a, off);
+    case X: case Y: case Tau: case E: case Nat: case Encoded: return ex;
+    case Var: return var_id((uint64_t)((int64_t)ex->u + off));
+    case Let: {
+        std::vector<std::pair<uint64_t, Expr>> vars;
+        for (const auto &v : ex->vars) vars.emplace_back((uint64_t)((int64_t)v.first + off), var_offset(v.second, off));
+        return let_(std::move(vars), var_offset(ex->a, off));
+    }
+    case App: return app((uint32_t)ex->u, var_offset(ex->a, off), var_offset(ex->b, off));
+    default: return mk(ex->tag, var_offset(ex->a, off), ex->b ? var_offset(ex->b, off) : nullptr, ex->u);
+    }
+}
 
 // ---- save (src/lib.rs:1216-1224) ---------------------------------------------------------------
 inline void encode_expr(const Expr &ex, std::vector<uint8_t> &out)

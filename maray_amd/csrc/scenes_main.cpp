@@ -99,6 +99,28 @@ static Color sdf(uint64_t size, bool authored = false)
     return {c, c, c};
 }
 
+// The reference's transforming and curve builders in one small picture (tests/scenes.py transforms() is the same scene by
+// the test builders): src/lib.rs:799-826, 1031-1070, 1127-1151, 845-850, 738-796
+static Color transforms(uint64_t size)
+{
+    Point2 p = {div(x(), nat(size)), div(y(), nat(size))};
+    Point4 centre = p4_same(half());
+    Expr quarter = div(nat(1), nat(4)), eighth = div(nat(1), nat(8));
+    Expr box = sd_inside(sd_box({quarter, eighth}));
+    box = rotate_at(scale_at(translate(box, p4_xy(centre)), p4_zw(centre), {div(nat(3), nat(2)), half()}), p4_xy(centre), rad_45());
+    Expr disk = translate(sd_inside(sd_circle(quarter)), p4_zw(centre));
+    Expr r = mul(subst2(set_xor(box, disk), p), nat(255));
+    Point2 curve = p2_cbez({nat(0), nat(0)}, {nat(1), nat(0)}, {nat(0), nat(1)}, {nat(1), nat(1)}, x());
+    Point2 spiral = p2_spiral(unit_to_rad(y()));
+    Expr g = mul(clamp_unit(subst2(p2_len(p2_sub(curve, spiral)), p)), nat(255));
+    std::array<Point2, 3> tri = {Point2{nat(0), nat(0)}, Point2{nat(1), nat(0)}, Point2{nat(0), nat(1)}};
+    Point2 back = p2_subst(from_barycentric(tri, to_barycentric(tri, {x(), y()})), p);
+    Expr u = var("u");
+    Expr body = var_offset(let_({{u->u, back[0]}}, mul(clamp_unit(u), nat(255))), 7);
+    if (var_range(body) != std::array<uint64_t, 2>{u->u + 7, u->u + 8}) { fprintf(stderr, "maray_scenes: var_range\n"); exit(1); }
+    return {r, g, body};
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) { fprintf(stderr, "usage: maray_scenes OUTDIR [SCENE ...]      (no SCENE: all of them)\n"); return 2; }
@@ -114,6 +136,7 @@ int main(int argc, char **argv)
         {"allops_4096", 4096, 4096, [] { return all_ops(4096, 4096); }},
         {"textured_4096", 4096, 4096, [] { return textured(4096); }},
         {"sdf_512", 512, 512, [] { return sdf(512); }},
+        {"transforms_256", 256, 256, [] { return transforms(256); }},
         {"sdf_512_authored", 512, 512, [] { return sdf(512, true); }},
         {"chess_board_1024", 1024, 1024, [] { return chess_board(1024); }},
         // examples/chess.rs as the example runs it, at its own size and natively at 4096 (what simplify

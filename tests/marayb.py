@@ -179,6 +179,86 @@ def subst_xy_deep(ex, p):
     return go(ex)
 
 
+# ---- the rest of the reference's authoring functions (each restated from the file:line it cites) -------------------
+def var(name):   # src/lib.rs:845-850: fnv::FnvHasher over str::hash = the bytes and a 0xff terminator
+    h = 0xcbf29ce484222325
+    for c in name.encode() + b'\xff':
+        h = ((h ^ c) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return var_id(h)
+
+
+def p2_abs(a): return [abs_(a[0]), abs_(a[1])]
+def p2_max(a, b): return [max_(a[0], b[0]), max_(a[1], b[1])]
+def p2_circle(ang): return [cos(ang), sin(ang)]                                          # :1031-1033
+def p2_spiral(ang): return p2_scale(p2_circle(ang), rad_to_unit(ang))                   # :1035-1037
+def p2_qbez(a, b, c, t): return p2_lerp(p2_lerp(a, b, t), p2_lerp(b, c, t), t)          # :1055-1059
+def p2_cbez(a, b, c, d, t): return p2_lerp(p2_qbez(a, b, c, t), p2_qbez(b, c, d, t), t)  # :1061-1065
+def p2_subst(p, off): return [subst2(p[0], off), subst2(p[1], off)]                     # :1067-1070
+def p4_same(v): return [v, v, v, v]                                                      # :1141-1151
+def p4_xy(p): return [p[0], p[1]]
+def p4_zw(p): return [p[2], p[3]]
+def translate(ex, off): return subst2(ex, p2_sub([x(), y()], off))                       # :799-801
+def scale(ex, s): return subst2(ex, p2_div([x(), y()], s))                               # :804-806
+def scale_at(ex, off, s): return translate(scale(translate(ex, p2_neg(off)), s), off)   # :809-811
+
+
+def rotate(ex, rad):   # :814-821
+    sn, cs = sin(rad), cos(rad)
+    ident = [x(), y()]
+    return subst2(ex, [p2_dot([cs, neg(sn)], ident), p2_dot([sn, cs], ident)])
+
+
+def rotate_at(ex, off, rad): return translate(rotate(translate(ex, p2_neg(off)), rad), off)   # :824-826
+
+
+def from_barycentric(tri, lam):   # :1127-1138
+    return [add(add(mul(lam[0], tri[0][0]), mul(lam[1], tri[1][0])), mul(lam[2], tri[2][0])),
+            add(add(mul(lam[0], tri[0][1]), mul(lam[1], tri[1][1])), mul(lam[2], tri[2][1]))]
+
+
+def sd_circle(r): return sub(p2_len([x(), y()]), r)                                      # src/sd.rs:20-22
+def sd_box(b):                                                                           # src/sd.rs:23-29
+    d = p2_sub(p2_abs([x(), y()]), b)
+    return add(p2_len(p2_max(d, [nat(0), nat(0)])), min_(max_(d[0], d[1]), nat(0)))
+def sd_inside(sd): return step(neg(sd))                                                  # src/sd.rs:51-53
+
+
+def var_range_union(a, b):   # :830-834
+    if a[1] - a[0] == 0: return b
+    if b[1] - b[0] == 0: return a
+    return [min(a[0], b[0]), max(a[1], b[1])]
+
+
+def var_range(ex):   # Expr::var_range, :738-764
+    t = ex[0]
+    if t in ('Arc', 'Decor'): return var_range(ex[1])
+    if t in ('X', 'Y', 'Tau', 'E', 'Nat'): return [0, 0]
+    if t == 'Var': return [ex[1], ex[1] + 1]
+    if t in UNARY: return var_range(ex[1])
+    if t in BINARY: return var_range_union(var_range(ex[1]), var_range(ex[2]))
+    if t == 'App': return var_range_union(var_range(ex[2]), var_range(ex[3]))
+    if t == 'Let':
+        r = var_range(ex[2])
+        for i, d in ex[1]:
+            r = var_range_union(r, [i, i + 1])
+            r = var_range_union(r, var_range(d))
+        return r
+    raise ValueError(t)
+
+
+def var_offset(ex, off):   # Expr::var_offset, :767-796
+    t = ex[0]
+    if t == 'Arc': return var_offset(ex[1], off)
+    if t in ('X', 'Y', 'Tau', 'E', 'Nat'): return ex
+    if t == 'Var': return ('Var', (ex[1] + off) & 0xFFFFFFFFFFFFFFFF)
+    if t in UNARY: return (t, var_offset(ex[1], off))
+    if t in BINARY: return (t, var_offset(ex[1], off), var_offset(ex[2], off))
+    if t == 'Decor': return ('Decor', var_offset(ex[1], off), ex[2])
+    if t == 'App': return ('App', ex[1], var_offset(ex[2], off), var_offset(ex[3], off))
+    if t == 'Let': return ('Let', tuple(((i + off) & 0xFFFFFFFFFFFFFFFF, var_offset(d, off)) for i, d in ex[1]), var_offset(ex[2], off))
+    raise ValueError(t)
+
+
 # ---- textures ids (src/textures.rs:14-23) ---------------------------------
 ALIGN = 5
 def channel(img, ch): return img * ALIGN + ch

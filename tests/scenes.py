@@ -80,3 +80,29 @@ def shapes_through_inf_and_nan():
     shape_a = mul(mul(mul(f3, f4), f1), heavy)
     shape_b = mul(mul(f3, max_(f2, f4)), mul(heavy, step(sub(y(), nat(3)))))
     return [mul(max_(shape_a, shape_b), nat(255)), mul(shape_a, add(x(), nat(1))), add(shape_b, mul(f1, nat(2)))]
+
+
+def transforms(size):
+    """The reference's transforming and curve builders in one small picture (src/lib.rs:799-826, 1031-1070, 1127-1151, 845-850,
+    738-796): R = a box scaled and rotated about the picture's centre XOR a disk, G = distance between a cubic Bezier point
+    (parameter x) and a spiral point (angle from y), B = a point sent to barycentric coordinates and back, through a Let whose
+    variable is named by `var` and moved by `var_offset`."""
+    from marayb import (clamp_unit, from_barycentric, half, let_, p2_cbez, p2_len, p2_spiral, p2_sub, p2_subst, p4_same, p4_xy,
+                        p4_zw, rad_45, rotate_at, scale_at, sd_box, sd_circle, sd_inside, set_xor, subst2, to_barycentric,
+                        translate, unit_to_rad, var, var_offset, var_range)
+    p = [div(x(), nat(size)), div(y(), nat(size))]
+    centre = p4_same(half())
+    quarter, eighth = div(nat(1), nat(4)), div(nat(1), nat(8))
+    box = sd_inside(sd_box([quarter, eighth]))
+    box = rotate_at(scale_at(translate(box, p4_xy(centre)), p4_zw(centre), [div(nat(3), nat(2)), half()]), p4_xy(centre), rad_45())
+    disk = translate(sd_inside(sd_circle(quarter)), p4_zw(centre))
+    r = mul(subst2(set_xor(box, disk), p), nat(255))
+    curve = p2_cbez([nat(0), nat(0)], [nat(1), nat(0)], [nat(0), nat(1)], [nat(1), nat(1)], x())
+    spiral = p2_spiral(unit_to_rad(y()))
+    g = mul(clamp_unit(subst2(p2_len(p2_sub(curve, spiral)), p)), nat(255))
+    tri = [[nat(0), nat(0)], [nat(1), nat(0)], [nat(0), nat(1)]]
+    back = p2_subst(from_barycentric(tri, to_barycentric(tri, [x(), y()])), p)
+    u = var('u')
+    body = var_offset(let_([(u[1], back[0])], mul(clamp_unit(u), nat(255))), 7)
+    assert var_range(body) == [u[1] + 7, u[1] + 8]
+    return [r, g, body]

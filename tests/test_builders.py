@@ -25,7 +25,8 @@ def scene_dir(tmp_path_factory):
 def test_cpp_builders_write_the_same_files_as_the_test_builders(scene_dir):
     want = {'radial_1024.maray': encode((1024, 1024), scenes.radial_gradient()),
             'allops_4096.maray': encode((4096, 4096), scenes.all_ops(4096, 4096)),
-            'textured_4096.maray': encode((4096, 4096), scenes.textured(4096))}
+            'textured_4096.maray': encode((4096, 4096), scenes.textured(4096)),
+            'transforms_256.maray': encode((256, 256), scenes.transforms(256))}
     for name, data in want.items():
         assert open(os.path.join(scene_dir, name), 'rb').read() == data, name
 
@@ -84,3 +85,37 @@ def test_chess_board_reconstruction_full_image_on_gpu(scene_dir):
     # a different association than the published picture's source: still only the two knife-edge rows differ
     assert diff.sum() <= 0.0004 * 1024 * 1024
     assert set(np.nonzero(diff.any(axis=1))[0].tolist()) <= {512, 704}
+
+
+def test_transforming_and_curve_builders(scene_dir):
+    """rotate / rotate_at / scale_at / translate, p2_cbez / p2_spiral / p2_subst, from_barycentric, p4_*, var / var_offset /
+    var_range (src/lib.rs:738-850, 1031-1070, 1127-1151) in one picture, written by the C++ builders byte for byte as by the
+    test builders (the test above), and meaning what they say when the oracle evaluates them: a point sent to barycentric
+    coordinates and back is itself; a box scaled by (3/2, 1/2) and turned by 45 degrees about the centre, XOR a disk, has
+    the disk's and the box's symmetry about the centre; the distance between the Bezier point and the spiral point is what
+    numpy computes from the closed forms; `var("u")` is Rust's FNV-1a of the name with str's 0xff terminator."""
+    from marayb import decode, var
+    from oracle_ffi import Scene as OScene
+    data = open(os.path.join(scene_dir, 'transforms_256.maray'), 'rb').read()
+    (w, h), color = decode(data)
+    assert (w, h) == (256, 256)
+    u = 0xcbf29ce484222325
+    for c in b'u\xff':
+        u = ((u ^ c) * 0x100000001b3) % 2**64
+    assert var('u') == ('Var', u) and color[2][0] == 'Let' and color[2][1][0][0] == (u + 7) % 2**64
+    img8, img64 = OScene(data).render_rows(256, 256, 0, 256)
+    yy, xx = np.mgrid[0:256, 0:256].astype(np.float64) / 256
+    # B: x -> barycentric -> x, clamped to the unit interval, times 255
+    assert np.allclose(img64[:, :, 2], np.clip(xx, 0, 1) * 255, atol=1e-9)
+    # R: a set (0 or 255), symmetric under the half turn about the centre pixel centre-to-centre (x, y) -> (256 - x, 256 - y)
+    r = img64[:, :, 0]
+    assert set(np.unique(r)) == {0.0, 255.0} and 0.05 < (r == 255).mean() < 0.5
+    assert (r[1:, 1:] != r[1:, 1:][::-1, ::-1]).mean() < 0.01               # (edges may fall on either side of a knife edge)
+    # G: |cbez(t = x) - spiral(angle = tau y)| from the closed forms
+    t = xx
+    def lerp(a, b, t): return a + (b - a) * t
+    def qb(a, b, c, t): return lerp(lerp(a, b, t), lerp(b, c, t), t)
+    bx, by = lerp(qb(0, 1, 0, t), qb(1, 0, 1, t), t), lerp(qb(0, 0, 1, t), qb(0, 1, 1, t), t)
+    ang = yy * 2 * np.pi
+    sx, sy = np.cos(ang) * (ang / (2 * np.pi)), np.sin(ang) * (ang / (2 * np.pi))
+    assert np.allclose(img64[:, :, 1], np.clip(np.hypot(bx - sx, by - sy), 0, 1) * 255, atol=1e-6)

@@ -257,6 +257,13 @@ def test_authored_scenes_simplify_compress_save_render(tmp_path):
     gpu_vs_oracle(open(psdf, 'rb').read(), 512, 512, [(0, 512)])
 
 
+def test_transforming_builders_scene(tmp_path):
+    """maray_scenes transforms_256 (rotate_at, scale_at, p2_cbez, p2_spiral, from_barycentric, var / var_offset: the rest of
+    the reference's authoring functions, tests/test_builders.py) on all three back-ends against the oracle, every pixel."""
+    (path,) = _maray_scenes(tmp_path, 'transforms_256')
+    gpu_vs_oracle(open(path, 'rb').read(), 256, 256, [(0, 256)])
+
+
 def test_cli_with_textures(tmp_path):
     """`maray -i scene.maray -o out.png -t a.png b.png` (/root/reference/examples/maray.rs:36-41, :58-65): textures read
     from PNG files by the binary, sampled on the device, the raster written as PNG -- against the oracle with the same
