@@ -217,9 +217,11 @@ struct JitBackend final : Backend {
         }
         const unsigned n_tx = (w + 255) / 256;
         const uint64_t n_tiles = (uint64_t)n_tx * rows_total;
-        // Tiles per wavefront.  Every tile of a program without guards costs the same: long strips, nothing to balance (config 2
-        // at 8192^2: 2.74 -> 2.88 TB/s with 8 tiles; only for the cheap four-wide sections, a narrow wavefront would live too
-        // long).  Else rows cost what they show (sky: nothing, board: 5x the average) and wavefronts are the unit of load
+        // Tiles per wavefront.  Every tile of a program without guards costs the same: nothing to balance, and a strip as long as
+        // the launch is deep -- a wavefront's tiles come one after the other, so a launch that fills the device once is as
+        // long as its longest strip (config 2, RGB8, us per frame with 1 / 2 / 4 / 8 / 16 tiles: 1024^2 3.03 / 3.14 / 3.53 (whole
+        // rows); 2048^2 6.86 / 6.70 / 6.99 / 7.63; 4096^2 19.4 / 18.4 / 18.4 / 21.5 / 20.2; 8192^2 65.7 / 63.0 / 63.0 / 60.1 / 69.5; only
+        // for the cheap four-wide sections, a narrow wavefront would live too long).  Else rows cost what they show (sky: nothing, board: 5x the average) and wavefronts are the unit of load
         // balance: a launch that fills the device only a few times over -- chess up to 2048^2 -- is a matter of how long its
         // longest wavefront lives, not of throughput: one tile per wavefront (1024^2 / 2048^2 / 4096^2 / 8192^2 with 1 tile:
         // 20.3 / 18.9 / 48.4 / 149 us per step, with 2: 25.5 / 24.8 / 42.3 / 138); a launch that fills it dozens of times over
@@ -227,7 +229,8 @@ struct JitBackend final : Backend {
         // (8192^2 / 16384^2 with 2 / 3 / 4 / 5 tiles: 138 / 123 / 119 / 139 and 517 / 487 / 497 / 566 us per step; 4096^2:
         // 42.2 / 55.5 / 44.6 / 46.9)
         const uint64_t device_slots = (uint64_t)n_cu * 4 * 7;
-        unsigned tiles = wide_all ? 8 : (n_tiles <= 4 * device_slots ? 1 : n_tiles <= 16 * device_slots ? 2 : 4);
+        unsigned tiles = wide_all ? (n_tiles <= device_slots ? 1 : n_tiles <= 4 * device_slots ? 2 : n_tiles <= 16 * device_slots ? 4 : 8)
+                                  : (n_tiles <= 4 * device_slots ? 1 : n_tiles <= 16 * device_slots ? 2 : 4);
         if (k_tiles) tiles = std::min(64u, k_tiles);
         if (n_gwords && n_gwords <= GW_INLINE_MAX) tiles = std::min(tiles, 64u / (n_gwords * guard_sub));      // a strip's guard words: one per lane
         tiles = std::max(1u, std::min(tiles, n_tx));
