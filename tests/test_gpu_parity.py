@@ -218,6 +218,55 @@ def test_chess_16384_in_one_launch_equals_the_interpreter_on_every_byte(chess_by
     assert out.returncode == 0 and 'config 4 ok' in out.stdout, out.stderr[-3000:]
 
 
+_TALL_ONE_LAUNCH = r"""
+import sys, numpy as np, torch
+sys.path[:0] = [%(root)r, %(tests)r]
+import maray_amd as M
+from fuzz_scenes import polygon_soup
+from marayb import encode
+from oracle_ffi import Scene as OScene
+w, h = 320, 70000                                   # 1.25 tiles a row; 70,000 rows: two grids (gridDim.y <= 65,535), no launch order
+data = encode((w, h), polygon_soup(33, 40, w, h, mixed=False))
+tape = M.Scene(data).lower()
+jit = M.Context(tape, backend=M.BACKEND_JIT)
+ref = M.Context(tape, backend=M.BACKEND_TAPE_SMEM)
+a = torch.full((h, w, 3), 9, dtype=torch.uint8, device='cuda')
+b = torch.full((h, w, 3), 7, dtype=torch.uint8, device='cuda')
+jit.render_rows_device(w, h, 0, h, d_rgb8=a.data_ptr())
+ref.render_rows_device(w, h, 0, h, d_rgb8=b.data_ptr())
+torch.cuda.synchronize()
+assert torch.equal(a, b), 'tall raster differs from the interpreter'
+img = a.cpu().numpy()
+assert img[::97].std() > 1.0                          # (a picture, not a constant)
+o = OScene(data)
+for y0, y1 in ((0, 3), (65530, 65540), (69990, 70000)):
+    want8, _ = o.render_rows(w, h, y0, y1, want_f64=False)
+    assert np.array_equal(img[y0:y1], want8), (y0, y1)
+# a range of rows that starts past the first grid and the f64 planes of it
+c8 = torch.zeros((600, w, 3), dtype=torch.uint8, device='cuda')
+c64 = torch.zeros((600, w, 3), dtype=torch.float64, device='cuda')
+jit.render_rows_device(w, h, 65400, 66000, d_rgb8=c8.data_ptr(), d_rgb64=c64.data_ptr())
+torch.cuda.synchronize()
+assert torch.equal(c8, a[65400:66000])
+_, want64 = o.render_rows(w, h, 65534, 65538)
+got64 = c64[134:138].cpu().numpy()
+assert np.array_equal(got64.view(np.uint64), want64.view(np.uint64))
+print('tall ok')
+"""
+
+
+def test_more_rows_than_a_grid_has_in_one_launch():
+    """70,000 rows of a 320-pixel-wide scene of guarded triangles in ONE device launch: more rows than gridDim.y takes
+    (65,535), so the launch is two grids and has no launch order; the ragged last tile of every row.  Every byte against
+    the interpreter's on the device, the oracle on bands at the top, across row 65,535 and at the bottom, f64 planes too."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, '-c', _TALL_ONE_LAUNCH % dict(root=os.path.dirname(here), tests=here)],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and 'tall ok' in out.stdout, out.stderr[-3000:]
+
+
 def _maray_scenes(tmp_path, *names):
     import subprocess
     exe = os.path.join(os.path.dirname(M.lib_path()), 'maray_scenes')
