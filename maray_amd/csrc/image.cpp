@@ -6,8 +6,8 @@
 // file's first bytes and decodes whatever it knows; `to_rgb8` then drops alpha, replicates grey and rounds 16-bit samples
 // to 8 (v * 255 + 32767) / 65535.  Here: PNG (png.cpp; every colour type and bit depth, interlaced or not), BMP
 // (uncompressed 8 / 24 / 32 bit, bottom-up or top-down), binary and plain PNM (P1 - P6), TGA (true colour, grey and
-// colour-mapped, raw or run-length encoded), QOI and farbfeld -- the formats that are a header and pixels.  JPEG, GIF,
-// WebP, TIFF and the HDR formats of that crate are entropy-coded codecs of their own and are not restated: a texture in
+// colour-mapped, raw or run-length encoded), QOI, farbfeld and GIF (the first frame) -- the formats that are a header and
+// pixels, or whose coding is exact (LZW).  JPEG, WebP, TIFF and the HDR formats of that crate are codecs of their own and are not restated: a texture in
 // one of them is MARAY_E_DECODE with the format's name ("convert it to PNG"), not a wrong picture.
 //
 // Sizes come from the file: every product is formed in 64 bits and bounded (2^20 pixels a side, the evaluators' own
@@ -245,6 +245,120 @@ void farbfeld(const std::vector<uint8_t> &b, Owned &out, uint32_t &w, uint32_t &
         for (int k = 0; k < 3; k++) out.p[i * 3 + k] = (uint8_t)to8(((unsigned)b[16 + i * 8 + 2 * k] << 8) | b[16 + i * 8 + 2 * k + 1]);
 }
 
+// ---- GIF (87a / 89a): the FIRST frame on the logical screen, as `image`'s GifDecoder hands it to `to_rgb8` ----
+// (gif crate, ColorOutput::RGBA: a pixel is its palette colour, the transparent index too -- only its alpha is 0, and
+// to_rgb8 drops alpha; the screen outside the frame is transparent black; an index past the palette leaves the pixel as
+// it was.)  LZW: codes of min_size + 1 .. 12 bits, least significant bit first, across the data sub-blocks; a full table
+// keeps decoding with 12-bit codes until the encoder clears it (deferred clear).
+void gif(const std::vector<uint8_t> &b, Owned &out, uint32_t &w, uint32_t &h)
+{
+    if (b.size() < 13) throw Fail{MARAY_E_DECODE, "truncated GIF header"};
+    w = le16(&b[6]); h = le16(&b[8]);
+    size_t pos = 13;
+    const uint8_t *gct = nullptr; size_t gct_n = 0;
+    if (b[10] & 0x80) {
+        gct_n = (size_t)2 << (b[10] & 7);
+        if (pos + gct_n * 3 > b.size()) throw Fail{MARAY_E_DECODE, "truncated GIF colour table"};
+        gct = &b[pos]; pos += gct_n * 3;
+    }
+    auto skip_sub_blocks = [&]() {
+        for (;;) {
+            if (pos >= b.size()) throw Fail{MARAY_E_DECODE, "truncated GIF block"};
+            const size_t n = b[pos++];
+            if (!n) return;
+            if (pos + n > b.size()) throw Fail{MARAY_E_DECODE, "truncated GIF block"};
+            pos += n;
+        }
+    };
+    for (;;) {
+        if (pos >= b.size()) throw Fail{MARAY_E_DECODE, "GIF without an image"};
+        const uint8_t tag = b[pos++];
+        if (tag == 0x3B) throw Fail{MARAY_E_DECODE, "GIF without an image"};
+        if (tag == 0x21) {                                  // extension: label, then sub-blocks (the graphic control one only
+            if (pos >= b.size()) throw Fail{MARAY_E_DECODE, "truncated GIF block"};      // carries what to_rgb8 drops)
+            pos++;
+            skip_sub_blocks();
+            continue;
+        }
+        if (tag != 0x2C) throw Fail{MARAY_E_DECODE, "unknown GIF block"};
+        break;
+    }
+    if (pos + 9 > b.size()) throw Fail{MARAY_E_DECODE, "truncated GIF image descriptor"};
+    const uint32_t fl = le16(&b[pos]), ft = le16(&b[pos + 2]), fw = le16(&b[pos + 4]), fh = le16(&b[pos + 6]);
+    const uint8_t packed = b[pos + 8];
+    pos += 9;
+    const uint8_t *pal = gct; size_t pal_n = gct_n;
+    if (packed & 0x80) {
+        pal_n = (size_t)2 << (packed & 7);
+        if (pos + pal_n * 3 > b.size()) throw Fail{MARAY_E_DECODE, "truncated GIF colour table"};
+        pal = &b[pos]; pos += pal_n * 3;
+    }
+    if (!pal) throw Fail{MARAY_E_DECODE, "GIF frame without a colour table"};
+    if (!fw || !fh || (uint64_t)fl + fw > w || (uint64_t)ft + fh > h) throw Fail{MARAY_E_DECODE, "GIF frame outside its logical screen"};
+    out.p = raster(w, h);
+    memset(out.p, 0, (size_t)w * h * 3);
+    if (pos >= b.size()) throw Fail{MARAY_E_DECODE, "truncated GIF image data"};
+    const unsigned min_size = b[pos++];
+    if (min_size < 1 || min_size > 11) throw Fail{MARAY_E_DECODE, "bad GIF code size"};      // (the gif crate rejects > 11 as well)
+    const unsigned clear = 1u << min_size, stop = clear + 1;
+    std::vector<uint16_t> prefix(4096);
+    std::vector<uint8_t> suffix(4096), first(4096), stack(4097);
+    for (unsigned i = 0; i < clear; i++) { prefix[i] = 0xFFFF; suffix[i] = (uint8_t)i; first[i] = (uint8_t)i; }
+    unsigned size = min_size + 1, next = clear + 2, prev = 0xFFFF;
+    uint32_t acc = 0; unsigned bits = 0;
+    size_t block_left = 0;
+    bool data_end = false;
+    const uint64_t n_px = (uint64_t)fw * fh;
+    uint64_t done = 0;
+    const bool interlaced = (packed & 0x40) != 0;
+    // frame pixel i -> raster position (interlace: rows 0 8 16 .., 4 12 .., 2 6 10 .., 1 3 5 ..)
+    std::vector<uint32_t> row_of;
+    if (interlaced) {
+        static const unsigned start[4] = {0, 4, 2, 1}, step[4] = {8, 8, 4, 2};
+        for (int p4 = 0; p4 < 4; p4++) for (uint32_t y = start[p4]; y < fh; y += step[p4]) row_of.push_back(y);
+    }
+    auto put = [&](uint8_t idx) {
+        if (done >= n_px) return;                           // (data past the frame's pixels is ignored)
+        const uint32_t fy = (uint32_t)(done / fw), fx = (uint32_t)(done % fw);
+        const uint32_t y = ft + (interlaced ? row_of[fy] : fy), x = fl + fx;
+        if (idx < pal_n) memcpy(out.p + ((size_t)y * w + x) * 3, pal + (size_t)idx * 3, 3);
+        done++;
+    };
+    while (done < n_px) {
+        while (bits < size && !data_end) {                  // refill from the sub-blocks
+            if (!block_left) {
+                if (pos >= b.size()) { data_end = true; break; }
+                block_left = b[pos++];
+                if (!block_left) { data_end = true; break; }
+                if (pos + block_left > b.size()) throw Fail{MARAY_E_DECODE, "truncated GIF image data"};
+            }
+            acc |= (uint32_t)b[pos++] << bits; bits += 8; block_left--;
+        }
+        if (bits < size) throw Fail{MARAY_E_DECODE, "GIF image data ends before its pixels do"};
+        const unsigned code = acc & ((1u << size) - 1);
+        acc >>= size; bits -= size;
+        if (code == clear) { size = min_size + 1; next = clear + 2; prev = 0xFFFF; continue; }
+        if (code == stop) throw Fail{MARAY_E_DECODE, "GIF image data ends before its pixels do"};
+        if (code > next || (code == next && prev == 0xFFFF)) throw Fail{MARAY_E_DECODE, "bad GIF code"};
+        // the string of `code` (or of prev + its own first symbol when code is the entry being defined), back to front
+        unsigned sp = 0, c = code;
+        if (code == next) { stack[sp++] = first[prev]; c = prev; }
+        while (c >= clear) {
+            if (c < clear + 2 || sp >= 4096) throw Fail{MARAY_E_DECODE, "bad GIF code"};
+            stack[sp++] = suffix[c]; c = prefix[c];
+        }
+        stack[sp++] = (uint8_t)c;
+        const uint8_t head = (uint8_t)c;
+        while (sp) put(stack[--sp]);
+        if (prev != 0xFFFF && next < 4096) {
+            prefix[next] = (uint16_t)prev; suffix[next] = head; first[next] = first[prev];
+            next++;
+            if (next == (1u << size) && size < 12) size++;
+        }
+        prev = code;
+    }
+}
+
 bool ends_with(const char *s, const char *suffix)
 {
     const size_t n = strlen(s), m = strlen(suffix);
@@ -271,11 +385,11 @@ extern "C" int maray_image_read(const char *path, uint8_t **rgb8_out, uint32_t *
         else if (b.size() >= 4 && !memcmp(b.data(), "qoif", 4)) qoi(b, out, w, h);
         else if (b.size() >= 8 && !memcmp(b.data(), "farbfeld", 8)) farbfeld(b, out, w, h);
         else if (b.size() >= 3 && b[0] == 0xFF && b[1] == 0xD8 && b[2] == 0xFF) throw Fail{MARAY_E_DECODE, "JPEG textures are not supported: convert the file to PNG"};
-        else if (b.size() >= 6 && (!memcmp(b.data(), "GIF87a", 6) || !memcmp(b.data(), "GIF89a", 6))) throw Fail{MARAY_E_DECODE, "GIF textures are not supported: convert the file to PNG"};
+        else if (b.size() >= 6 && (!memcmp(b.data(), "GIF87a", 6) || !memcmp(b.data(), "GIF89a", 6))) gif(b, out, w, h);
         else if (b.size() >= 12 && !memcmp(b.data(), "RIFF", 4) && !memcmp(&b[8], "WEBP", 4)) throw Fail{MARAY_E_DECODE, "WebP textures are not supported: convert the file to PNG"};
         else if (b.size() >= 4 && (!memcmp(b.data(), "II*\0", 4) || !memcmp(b.data(), "MM\0*", 4))) throw Fail{MARAY_E_DECODE, "TIFF textures are not supported: convert the file to PNG"};
         else if (ends_with(path, ".tga") || (b.size() >= 26 && !memcmp(&b[b.size() - 18], "TRUEVISION-XFILE", 16))) tga(b, out, w, h);       // TGA has no signature up front
-        else throw Fail{MARAY_E_DECODE, "texture file format not recognised (PNG, BMP, PNM, TGA, QOI and farbfeld are read)"};
+        else throw Fail{MARAY_E_DECODE, "texture file format not recognised (PNG, BMP, PNM, TGA, QOI, farbfeld and GIF are read)"};
         *rgb8_out = out.release(); *w_out = w; *h_out = h;
         return MARAY_OK;
     }

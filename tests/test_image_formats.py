@@ -1,5 +1,5 @@
 """Texture files: `image::open(file).to_rgb8()` (/root/reference/examples/maray.rs:58-65) takes whatever the `image` crate
-knows; maray_image_read takes PNG (every colour type and depth, interlaced too), BMP, PNM, TGA, QOI and farbfeld, told from
+knows; maray_image_read takes PNG (every colour type and depth, interlaced too), BMP, PNM, TGA, QOI, farbfeld and GIF, told from
 the file's first bytes, and names the codecs it does not restate.  Reference decodings: Pillow, and the formats' own
 definitions where Pillow has no writer."""
 import os
@@ -141,10 +141,91 @@ def test_qoi_and_farbfeld(tmp_path, pic):
     assert np.array_equal(M.image_read(p), pic)
 
 
+def _gif(screen, frame, indices, palette, min_size, codes, local=False, gce=None, interlace=False, extra=b''):
+    """A GIF by hand: screen (w, h), frame (left, top, w, h), the LZW codes given as (value, bits) pairs."""
+    (sw, sh), (fl, ft, fw, fh) = screen, frame
+    bits = 0
+    nbits = 0
+    data = bytearray()
+    for v, n in codes:
+        bits |= v << nbits
+        nbits += n
+        while nbits >= 8:
+            data.append(bits & 255)
+            bits >>= 8
+            nbits -= 8
+    if nbits:
+        data.append(bits & 255)
+    blocks = b''.join(bytes([len(data[i:i + 255])]) + bytes(data[i:i + 255]) for i in range(0, len(data), 255)) + b'\0'
+    pal = bytes(palette)
+    size = {2: 0, 4: 1, 8: 2, 16: 3}[len(palette) // 3]
+    out = b'GIF89a' + struct.pack('<HHBBB', sw, sh, 0 if local else 0x80 | size, 0, 0) + (b'' if local else pal)
+    if gce is not None:
+        out += b'\x21\xF9\x04' + struct.pack('<BHB', 1, 0, gce) + b'\0'
+    out += extra + b'\x2C' + struct.pack('<HHHHB', fl, ft, fw, fh, (0x80 | size if local else 0) | (0x40 if interlace else 0)) + (pal if local else b'')
+    return out + bytes([min_size]) + blocks + b'\x3B'
+
+
+def test_gif(tmp_path):
+    """GIF: the first frame on the logical screen as `image`'s GifDecoder + to_rgb8 give it -- palette colours (the
+    transparent index keeps its colour: only its alpha is 0 and to_rgb8 drops alpha), black outside the frame.  Pillow's
+    files (interlaced or not, 2 to 256 colours, long runs and noise: clears and a full code table), an animation (first
+    frame), and files made by hand: a frame smaller than the screen, a local colour table, a comment extension, an index
+    past the palette."""
+    rng = np.random.default_rng(5)
+    for (w, h, inter, ncol) in ((37, 23, False, 256), (64, 64, True, 16), (200, 133, False, 2), (1, 1, False, 4), (300, 7, True, 200), (513, 257, False, 256)):
+        idx = rng.integers(0, ncol, (h, w), dtype=np.uint8)
+        if w > 100:
+            idx[:, :w // 2] = idx[0, 0]
+        pal = rng.integers(0, 256, (ncol, 3), dtype=np.uint8)
+        im = Image.fromarray(idx, 'P')
+        im.putpalette(pal.tobytes())
+        p = str(tmp_path / ('p_%d_%d.gif' % (w, h)))
+        im.save(p, interlace=inter)
+        assert np.array_equal(M.image_read(p), pal[idx]), (w, h)
+    # transparency: index 3 is transparent and still reads as its palette colour
+    idx = rng.integers(0, 8, (20, 30), dtype=np.uint8)
+    pal = rng.integers(0, 256, (8, 3), dtype=np.uint8)
+    im = Image.fromarray(idx, 'P')
+    im.putpalette(pal.tobytes())
+    p = str(tmp_path / 'transparent.gif')
+    im.save(p, transparency=3)
+    assert b'\x21\xF9' in open(p, 'rb').read() and np.array_equal(M.image_read(p), pal[idx])
+    # an animation: the first frame
+    frames = [Image.fromarray(rng.integers(0, 4, (12, 12), dtype=np.uint8) * 60, 'L').convert('P') for _ in range(3)]
+    p = str(tmp_path / 'anim.gif')
+    frames[0].save(p, save_all=True, append_images=frames[1:], duration=50)
+    assert np.array_equal(M.image_read(p), np.asarray(frames[0].convert('RGB')))
+    # by hand: 2-bit codes (min size 2: clear = 4, end = 5), a 2 x 2 frame at (1, 1) of a 4 x 3 screen, local colour table,
+    # a comment extension in front, index 3 past a... palette of four: (10,20,30) (40,50,60) (70,80,90) (1,2,3)
+    pal4 = [10, 20, 30, 40, 50, 60, 70, 80, 90, 1, 2, 3]
+    codes = [(4, 3), (0, 3), (1, 3), (2, 3), (3, 4), (5, 4)]                 # clear, the four pixels, end (the table reaches 8 entries after the third pixel: 4-bit codes from there)
+    want = np.zeros((3, 4, 3), np.uint8)
+    want[1, 1], want[1, 2], want[2, 1], want[2, 2] = (10, 20, 30), (40, 50, 60), (70, 80, 90), (1, 2, 3)
+    for local in (False, True):
+        p = str(tmp_path / ('hand_%d.gif' % local))
+        open(p, 'wb').write(_gif((4, 3), (1, 1, 2, 2), None, pal4, 2, codes, local=local, gce=2, extra=b'\x21\xFE\x05hello\0'))
+        assert np.array_equal(M.image_read(p), want), local
+    # ... and a code that is its own definition (KwKwK): pixels 0 0 0 0 0 0 as codes 0, 6 (= "0 0", being defined), 7?  no: 0, 6, 6
+    p = str(tmp_path / 'kwkwk.gif')
+    open(p, 'wb').write(_gif((5, 1), (0, 0, 5, 1), None, pal4, 2, [(4, 3), (0, 3), (6, 3), (6, 3), (5, 4)]))
+    assert np.array_equal(M.image_read(p), np.tile(np.array([10, 20, 30], np.uint8), (1, 5, 1)))
+    # broken: a frame outside its screen, a code past the table, data that ends early, no image at all
+    bad = {'outside.gif': _gif((4, 3), (3, 1, 2, 2), None, pal4, 2, codes), 'code.gif': _gif((2, 2), (0, 0, 2, 2), None, pal4, 2, [(4, 3), (7, 3), (5, 3)]),
+           'early.gif': _gif((2, 2), (0, 0, 2, 2), None, pal4, 2, [(4, 3), (0, 3), (5, 3)]), 'none.gif': b'GIF89a' + struct.pack('<HHBBB', 2, 2, 0, 0, 0) + b'\x3B',
+           'trunc.gif': _gif((2, 2), (0, 0, 2, 2), None, pal4, 2, codes)[:-6], 'size.gif': _gif((2, 2), (0, 0, 2, 2), None, pal4, 12, codes)}
+    for name, data in bad.items():
+        p = str(tmp_path / name)
+        open(p, 'wb').write(data)
+        with pytest.raises(M.MarayError) as e:
+            M.image_read(p)
+        assert e.value.code == -3, (name, str(e.value))
+
+
 def test_formats_not_restated_and_broken_files_are_errors(tmp_path, pic):
     Image.fromarray(pic).save(str(tmp_path / 'a.jpg'))
-    Image.fromarray(pic).save(str(tmp_path / 'a.gif'))
-    for name, word in (('a.jpg', 'JPEG'), ('a.gif', 'GIF')):
+    Image.fromarray(pic).save(str(tmp_path / 'a.tif'))
+    for name, word in (('a.jpg', 'JPEG'), ('a.tif', 'TIFF')):
         with pytest.raises(M.MarayError) as e:
             M.image_read(str(tmp_path / name))
         assert e.value.code == -3 and word in str(e.value) and 'convert' in str(e.value)

@@ -130,6 +130,24 @@ def test_image_readers_with_crafted_headers_under_asan_ubsan(tmp_path):
         'qoi_huge.qoi': b'qoif' + struct.pack('>IIBB', 0xFFFFFFFF, 0xFFFFFFFF, 4, 0) + bytes(16),
         'ff_short.ff': b'farbfeld' + struct.pack('>II', 100, 100) + bytes(64), 'ff_huge.ff': b'farbfeld' + struct.pack('>II', 0xFFFFFFFF, 2),
     }
+    # GIF: Pillow's files, and the same with bytes knocked out / the header lying / random LZW data
+    for name, kw in (('good_a.gif', {}), ('good_i.gif', {'interlace': True})):
+        p = str(tmp_path / name)
+        im.convert('P', palette=Image.ADAPTIVE, colors=32).save(p, **kw)
+        paths.append(p)
+    big = Image.fromarray(rng.integers(0, 256, (120, 160), dtype=np.uint8), 'P')
+    big.putpalette(bytes(rng.integers(0, 256, 768, dtype=np.uint8)))
+    big.save(str(tmp_path / 'good_full_table.gif'))
+    paths.append(str(tmp_path / 'good_full_table.gif'))
+    g = open(str(tmp_path / 'good_full_table.gif'), 'rb').read()
+    files.update({
+        'gif_trunc1.gif': g[:20], 'gif_trunc2.gif': g[:len(g) // 2], 'gif_trunc3.gif': g[:800],
+        'gif_screen.gif': g[:6] + struct.pack('<HH', 4, 4) + g[10:],                      # a frame larger than its logical screen
+        'gif_huge.gif': g[:6] + struct.pack('<HH', 0xFFFF, 0xFFFF) + g[10:13] + b'\x3B',
+        'gif_noise.gif': g[:13 + 768 + 10] + bytes([8]) + b''.join(bytes([255]) + bytes(rng.integers(0, 256, 255, dtype=np.uint8)) for _ in range(40)) + b'\0\x3B',
+        'gif_min.gif': g[:13 + 768 + 10] + bytes([13]) + g[13 + 768 + 11:],
+        'gif_ext.gif': g[:13 + 768] + b'\x21\xFE\xFF' + bytes(10),
+    })
     for name, data in files.items():
         p = str(tmp_path / name)
         open(p, 'wb').write(data)
