@@ -85,6 +85,16 @@ inline Expr add(Expr a, Expr b) { return mk(Add, a, b); }
 inline Expr mul(Expr a, Expr b) { return mk(Mul, a, b); }
 inline Expr sub(Expr a, Expr b) { return add(a, neg(b)); }
 inline Expr div(Expr a, Expr b) { return mul(a, recip(b)); }
+// the operators of src/lib.rs:151-194 (Expr with Expr, Expr with a natural number, unary minus); found through Node's namespace
+inline Expr operator/(const Expr &a, const Expr &b) { return div(a, b); }
+inline Expr operator/(const Expr &a, uint64_t b) { return div(a, nat(b)); }
+inline Expr operator*(const Expr &a, const Expr &b) { return mul(a, b); }
+inline Expr operator*(const Expr &a, uint64_t b) { return mul(a, nat(b)); }
+inline Expr operator+(const Expr &a, const Expr &b) { return add(a, b); }
+inline Expr operator+(const Expr &a, uint64_t b) { return add(a, nat(b)); }
+inline Expr operator-(const Expr &a, const Expr &b) { return sub(a, b); }
+inline Expr operator-(const Expr &a, uint64_t b) { return sub(a, nat(b)); }
+inline Expr operator-(const Expr &a) { return neg(a); }
 inline Expr let_(std::vector<std::pair<uint64_t, Expr>> vars, Expr body)
 {
     auto n = std::make_shared<Node>();

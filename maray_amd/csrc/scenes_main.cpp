@@ -137,6 +137,8 @@ int main(int argc, char **argv)
         {"textured_4096", 4096, 4096, [] { return textured(4096); }},
         {"sdf_512", 512, 512, [] { return sdf(512); }},
         {"transforms_256", 256, 256, [] { return transforms(256); }},
+        // examples/test7.rs:5-7: `nat(255) * x() / nat(size[0])`, the operators being mul and div (src/lib.rs: impl Mul / Div for Expr)
+        {"test7_128", 128, 128, [] { Expr c = nat(255) * x() / nat(128); return Color{c, c, c}; }},
         {"sdf_512_authored", 512, 512, [] { return sdf(512, true); }},
         {"chess_board_1024", 1024, 1024, [] { return chess_board(1024); }},
         // examples/chess.rs as the example runs it, at its own size and natively at 4096 (what simplify

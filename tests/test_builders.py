@@ -11,7 +11,7 @@ import maray_amd as M
 import scenes
 import tape_eval
 from conftest import GOLDEN
-from marayb import encode
+from marayb import div, encode, mul, nat, x
 
 
 @pytest.fixture(scope='module')
@@ -26,7 +26,8 @@ def test_cpp_builders_write_the_same_files_as_the_test_builders(scene_dir):
     want = {'radial_1024.maray': encode((1024, 1024), scenes.radial_gradient()),
             'allops_4096.maray': encode((4096, 4096), scenes.all_ops(4096, 4096)),
             'textured_4096.maray': encode((4096, 4096), scenes.textured(4096)),
-            'transforms_256.maray': encode((256, 256), scenes.transforms(256))}
+            'transforms_256.maray': encode((256, 256), scenes.transforms(256)),
+            'test7_128.maray': encode((128, 128), [div(mul(nat(255), x()), nat(128))] * 3)}      # examples/test7.rs:5-7
     for name, data in want.items():
         assert open(os.path.join(scene_dir, name), 'rb').read() == data, name
 

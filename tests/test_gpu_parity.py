@@ -313,6 +313,18 @@ def test_transforming_builders_scene(tmp_path):
     gpu_vs_oracle(open(path, 'rb').read(), 256, 256, [(0, 256)])
 
 
+def test_example_test7_gradient(tmp_path):
+    """examples/test7.rs: `nat(255) * x() / nat(128)` at 128 x 128 through maray_gen with a progress report every 10 rows
+    (Report::Row(10), :9): the raster is floor(255 x / 128) in every channel and row."""
+    (path,) = _maray_scenes(tmp_path, 'test7_128')
+    data = open(path, 'rb').read()
+    gpu_vs_oracle(data, 128, 128, [(0, 128)])
+    want = np.repeat(np.repeat((255 * np.arange(128) // 128).astype(np.uint8)[None, :, None], 128, axis=0), 3, axis=2)
+    out = str(tmp_path / 'test7.png')
+    M.gen(M.Scene(data), out, backend=M.BACKEND_JIT, report_kind=M.api.REPORT_ROW, report_value=10)
+    assert np.array_equal(M.png_read(out), want)
+
+
 def test_cli_with_textures(tmp_path):
     """`maray -i scene.maray -o out.png -t a.png b.png` (/root/reference/examples/maray.rs:36-41, :58-65): textures read
     from PNG files by the binary, sampled on the device, the raster written as PNG -- against the oracle with the same
