@@ -96,6 +96,9 @@ def test_polygon_soups_lowering_vs_oracle():
 
 @pytest.mark.gpu
 def test_polygon_soups_gpu_vs_oracle():
+    """Six soups of 70 polygons (one tree, shapes shared by two channels' trees, a colour per shape): the three evaluators
+    agree on every pixel (u8 and f64 planes), and the oracle -- six seconds a soup for the whole raster, which was most of
+    this test -- is asked for three bands of rows (top, middle, bottom)."""
     from fuzz_scenes import polygon_soup
     w, h = 1024, 200
     cases = []
@@ -104,13 +107,20 @@ def test_polygon_soups_gpu_vs_oracle():
         cases.append((seed, data, M.Scene(data).lower()))
     jit = _jit_contexts([(tape, None) for _, _, tape in cases])
     for (seed, data, tape), jctx in zip(cases, jit):
-        want8, want64 = OScene(data).render_rows(w, h, 0, h)
+        got = {}
         for b in (M.BACKEND_JIT, M.BACKEND_TAPE, M.BACKEND_TAPE_SMEM):
             ctx = jctx if b == M.BACKEND_JIT else M.Context(tape, backend=b)
-            got8, got64 = ctx.render_rows(w, h, 0, h)
+            got[b] = ctx.render_rows(w, h, 0, h)
             ctx.close()
-            assert same_f64(got64, want64), (seed, b)
-            assert np.array_equal(got8, want8), (seed, b)
+        ref8, ref64 = got[M.BACKEND_TAPE_SMEM]
+        for b in (M.BACKEND_JIT, M.BACKEND_TAPE):
+            assert same_f64(got[b][1], ref64), (seed, b)
+            assert np.array_equal(got[b][0], ref8), (seed, b)
+        o = OScene(data)
+        for y0, y1 in ((0, 8), (96, 104), (192, 200)):
+            want8, want64 = o.render_rows(w, h, y0, y1)
+            assert same_f64(ref64[y0:y1], want64), (seed, y0)
+            assert np.array_equal(ref8[y0:y1], want8), (seed, y0)
 
 
 @pytest.mark.gpu
@@ -144,6 +154,6 @@ def test_a_thousand_triangles_gpu_vs_oracle():
         assert np.array_equal(got8, want8), mode
         assert same_f64(got64, want64), mode
     o = OScene(data)
-    for y0, y1 in ((0, 4), (317, 323), (636, 640)):
+    for y0, y1 in ((0, 2), (318, 321), (638, 640)):
         o8, o64 = o.render_rows(w, h, y0, y1)
         assert np.array_equal(want8[y0:y1], o8) and same_f64(want64[y0:y1], o64), y0
