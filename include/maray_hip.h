@@ -269,8 +269,9 @@ int maray_gen(const maray_scene *s, const maray_texture *tex, uint32_t n_tex,
 int maray_png_write(const char *path, const uint8_t *rgb8, uint32_t w, uint32_t h);
 int maray_png_read(const char *path, uint8_t **rgb8_out, uint32_t *w, uint32_t *h);   /* free with maray_free */
 /* `image::open(file).unwrap().to_rgb8()` (examples/maray.rs:58-65): a texture in any format this library reads -- told from
- * the file's first bytes like the `image` crate does: PNG, BMP, PNM (P1 - P6), TGA, QOI, farbfeld, GIF (the first frame)
- * -- as RGB8 (alpha dropped, grey replicated, 16-bit samples rounded).  JPEG / WebP / TIFF: MARAY_E_DECODE naming the format. */
+ * the file's first bytes like the `image` crate does: PNG, BMP, PNM (P1 - P6), TGA, QOI, farbfeld, GIF (the first frame),
+ * TIFF (grey / RGB strips) -- as RGB8 (alpha dropped, grey replicated, 16-bit samples rounded).  JPEG / WebP:
+ * MARAY_E_DECODE naming the format. */
 int maray_image_read(const char *path, uint8_t **rgb8_out, uint32_t *w, uint32_t *h);   /* free with maray_free */
 void maray_free(void *p);
 

@@ -18,7 +18,7 @@ static void usage()
             "  -c, --cpus <cpus>            Number of CPU cores (accepted, unused)\n"
             "  -i, --input <input>          Input file `*.maray`\n"
             "  -o, --output <output>        Output file `*.png`\n"
-            "  -t, --textures <textures>... Texture files (PNG, BMP, PNM, TGA, QOI, farbfeld, GIF)\n"
+            "  -t, --textures <textures>... Texture files (PNG, BMP, PNM, TGA, QOI, farbfeld, GIF, TIFF)\n"
             "      --gpus <n>               Number of MI355X devices (default: all)\n"
             "      --backend <b>            auto | jit | tape | tape-smem (default: auto)\n");
 }

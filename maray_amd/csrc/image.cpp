@@ -6,12 +6,16 @@
 // file's first bytes and decodes whatever it knows; `to_rgb8` then drops alpha, replicates grey and rounds 16-bit samples
 // to 8 (v * 255 + 32767) / 65535.  Here: PNG (png.cpp; every colour type and bit depth, interlaced or not), BMP
 // (uncompressed 8 / 24 / 32 bit, bottom-up or top-down), binary and plain PNM (P1 - P6), TGA (true colour, grey and
-// colour-mapped, raw or run-length encoded), QOI, farbfeld and GIF (the first frame) -- the formats that are a header and
-// pixels, or whose coding is exact (LZW).  JPEG, WebP, TIFF and the HDR formats of that crate are codecs of their own and are not restated: a texture in
+// colour-mapped, raw or run-length encoded), QOI, farbfeld, GIF (the first frame) and TIFF (grey / RGB strips, 8 or 16 bits,
+// uncompressed, LZW, Deflate, PackBits) -- the formats that are a header and pixels, or whose coding is exact.  JPEG, WebP
+// and the HDR formats of that crate are codecs of their own and are not restated: a texture in
 // one of them is MARAY_E_DECODE with the format's name ("convert it to PNG"), not a wrong picture.
 //
 // Sizes come from the file: every product is formed in 64 bits and bounded (2^20 pixels a side, the evaluators' own
 // limit; the pixel data the header promises must be there) before anything is allocated or indexed.
+#include <zlib.h>
+
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -41,6 +45,16 @@ uint8_t *raster(uint32_t w, uint32_t h)
     uint8_t *p = (uint8_t *)malloc((size_t)w * h * 3);
     if (!p) throw Fail{MARAY_E_INTERNAL, "out of memory"};
     return p;
+}
+
+// zlib stream -> at most *n bytes of dst; *n = what arrived (a strip's last rows may be short of the nominal size)
+bool inflate_into(const uint8_t *src, size_t src_n, uint8_t *dst, size_t *n)
+{
+    uLongf got = (uLongf)*n;
+    const int rc = uncompress(dst, &got, src, (uLong)src_n);
+    if (rc != Z_OK && rc != Z_BUF_ERROR) return false;       // (Z_BUF_ERROR: more data than the rows need -- the rows are there)
+    *n = (size_t)got;
+    return true;
 }
 
 struct Owned {          // the raster until it is handed to the caller
@@ -359,6 +373,153 @@ void gif(const std::vector<uint8_t> &b, Owned &out, uint32_t &w, uint32_t &h)
     }
 }
 
+// ---- TIFF (baseline + LZW / Deflate / PackBits, strips): the first image of the file ----
+// What `image`'s TiffDecoder + to_rgb8 give for it: grey (WhiteIsZero inverted) and RGB, 8 or 16 bits a sample, extra
+// samples (alpha) dropped, horizontal differencing undone.  Tiles, palettes, CMYK / YCbCr / Lab, planar layouts and
+// samples of other widths are named and refused.
+struct Tiff {
+    const std::vector<uint8_t> &b;
+    bool big;
+    uint32_t u16(size_t at) const { if (at + 2 > b.size()) throw Fail{MARAY_E_DECODE, "truncated TIFF"}; return big ? ((uint32_t)b[at] << 8) | b[at + 1] : le16(&b[at]); }
+    uint32_t u32(size_t at) const { if (at + 4 > b.size()) throw Fail{MARAY_E_DECODE, "truncated TIFF"}; return big ? be32(&b[at]) : le32(&b[at]); }
+    // the values of a SHORT / LONG field (type 3 / 4), inline or behind its offset
+    std::vector<uint32_t> values(size_t entry) const {
+        const uint32_t type = u16(entry + 2), n = u32(entry + 4);
+        if (type != 3 && type != 4) throw Fail{MARAY_E_DECODE, "TIFF field of an unexpected type"};
+        const size_t sz = type == 3 ? 2 : 4;
+        if ((uint64_t)n * sz > b.size()) throw Fail{MARAY_E_DECODE, "truncated TIFF"};
+        size_t at = (uint64_t)n * sz <= 4 ? entry + 8 : u32(entry + 8);
+        std::vector<uint32_t> v(n);
+        for (uint32_t i = 0; i < n; i++, at += sz) v[i] = type == 3 ? u16(at) : u32(at);
+        return v;
+    }
+};
+
+// TIFF's LZW: codes of 9 .. 12 bits, most significant bit first, 256 = clear, 257 = end, the width grows one code early
+void tiff_lzw(const uint8_t *src, size_t n, std::vector<uint8_t> &out, size_t want)
+{
+    std::vector<uint16_t> prefix(4096);
+    std::vector<uint8_t> suffix(4096), first(4096), stack(4097);
+    for (unsigned i = 0; i < 256; i++) { prefix[i] = 0xFFFF; suffix[i] = (uint8_t)i; first[i] = (uint8_t)i; }
+    unsigned size = 9, next = 258, prev = 0xFFFF;
+    uint32_t acc = 0; unsigned bits = 0; size_t pos = 0;
+    while (out.size() < want) {
+        while (bits < size && pos < n) { acc = (acc << 8) | src[pos++]; bits += 8; }
+        if (bits < size) break;                               // (a strip may end without the end code)
+        const unsigned code = (acc >> (bits - size)) & ((1u << size) - 1);
+        bits -= size;
+        if (code == 256) { size = 9; next = 258; prev = 0xFFFF; continue; }
+        if (code == 257) break;
+        if (code > next || (code == next && prev == 0xFFFF) || (code >= 256 && code < 258)) throw Fail{MARAY_E_DECODE, "bad TIFF LZW code"};
+        unsigned sp = 0, c = code;
+        if (code == next) { stack[sp++] = first[prev]; c = prev; }
+        while (c >= 258) { if (sp >= 4096) throw Fail{MARAY_E_DECODE, "bad TIFF LZW code"}; stack[sp++] = suffix[c]; c = prefix[c]; }
+        if (c >= 256) throw Fail{MARAY_E_DECODE, "bad TIFF LZW code"};
+        stack[sp++] = (uint8_t)c;
+        const uint8_t head = (uint8_t)c;
+        while (sp && out.size() < want) out.push_back(stack[--sp]);
+        if (prev != 0xFFFF && next < 4096) {
+            prefix[next] = (uint16_t)prev; suffix[next] = head; first[next] = first[prev];
+            next++;
+            if (next + 1 == (1u << size) && size < 12) size++;
+        }
+        prev = code;
+    }
+}
+
+void tiff(const std::vector<uint8_t> &b, Owned &out, uint32_t &w, uint32_t &h)
+{
+    const Tiff t{b, b[0] == 'M'};
+    size_t ifd = t.u32(4);
+    const uint32_t n_entries = t.u16(ifd);
+    uint32_t bits = 1, comp = 1, photo = 0xFFFF, spp = 1, rps = 0xFFFFFFFFu, planar = 1, predictor = 1;
+    bool bits_same = true, tiled = false;
+    std::vector<uint32_t> offsets, counts;
+    w = h = 0;
+    for (uint32_t i = 0; i < n_entries; i++) {
+        const size_t e = ifd + 2 + (size_t)i * 12;
+        const uint32_t tag = t.u16(e);
+        auto one = [&]() -> uint32_t { const auto v = t.values(e); if (v.empty()) throw Fail{MARAY_E_DECODE, "empty TIFF field"}; return v[0]; };
+        switch (tag) {
+        case 256: w = one(); break;
+        case 257: h = one(); break;
+        case 258: { const auto v = t.values(e); if (v.empty()) throw Fail{MARAY_E_DECODE, "bad TIFF BitsPerSample"}; bits = v[0]; for (uint32_t x : v) bits_same &= x == bits; } break;
+        case 259: comp = one(); break;
+        case 262: photo = one(); break;
+        case 273: offsets = t.values(e); break;
+        case 277: spp = one(); break;
+        case 278: rps = one(); break;
+        case 279: counts = t.values(e); break;
+        case 284: planar = one(); break;
+        case 317: predictor = one(); break;
+        case 322: case 323: case 324: case 325: tiled = true; break;
+        default: break;
+        }
+    }
+    if (tiled) throw Fail{MARAY_E_DECODE, "tiled TIFF files are not supported: convert the file to PNG"};
+    if (photo == 3) throw Fail{MARAY_E_DECODE, "palette TIFF files are not supported: convert the file to PNG"};
+    if (photo > 2) throw Fail{MARAY_E_DECODE, "TIFF colour spaces other than grey and RGB are not supported: convert the file to PNG"};
+    if (!bits_same || (bits != 8 && bits != 16)) throw Fail{MARAY_E_DECODE, "TIFF samples of 8 or 16 bits are read, not others: convert the file to PNG"};
+    const uint32_t colour = photo == 2 ? 3u : 1u;
+    if (spp < colour || spp > 8 || (planar != 1 && spp > 1)) throw Fail{MARAY_E_DECODE, "unsupported TIFF sample layout"};
+    if (predictor != 1 && predictor != 2) throw Fail{MARAY_E_DECODE, "unsupported TIFF predictor"};
+    if (comp != 1 && comp != 5 && comp != 8 && comp != 32946 && comp != 32773) throw Fail{MARAY_E_DECODE, "unsupported TIFF compression: convert the file to PNG"};
+    out.p = raster(w, h);
+    if (!rps) throw Fail{MARAY_E_DECODE, "bad TIFF RowsPerStrip"};
+    rps = std::min(rps, h);
+    const uint32_t n_strips = (h + rps - 1) / rps;
+    if (offsets.size() < n_strips || counts.size() < n_strips) throw Fail{MARAY_E_DECODE, "TIFF strip table shorter than the image"};
+    const size_t bps = bits / 8, row_bytes = (size_t)w * spp * bps;
+    std::vector<uint8_t> strip;
+    for (uint32_t s = 0; s < n_strips; s++) {
+        const uint32_t rows = std::min(rps, h - s * rps);
+        const size_t want = row_bytes * rows;
+        if ((uint64_t)offsets[s] + counts[s] > b.size()) throw Fail{MARAY_E_DECODE, "TIFF strip outside the file"};
+        const uint8_t *src = b.data() + offsets[s];
+        strip.clear();
+        if (comp == 1) { if (counts[s] < want) throw Fail{MARAY_E_DECODE, "TIFF strip shorter than its rows"}; strip.assign(src, src + want); }
+        else if (comp == 5) { strip.reserve(want); tiff_lzw(src, counts[s], strip, want); }
+        else if (comp == 32773) {                              // PackBits
+            size_t pos = 0;
+            while (strip.size() < want && pos < counts[s]) {
+                const int8_t c = (int8_t)src[pos++];
+                if (c >= 0) { const size_t n = (size_t)c + 1; if (pos + n > counts[s]) throw Fail{MARAY_E_DECODE, "truncated TIFF PackBits data"}; strip.insert(strip.end(), src + pos, src + pos + n); pos += n; }
+                else if (c != -128) { if (pos >= counts[s]) throw Fail{MARAY_E_DECODE, "truncated TIFF PackBits data"}; strip.insert(strip.end(), (size_t)(1 - c), src[pos++]); }
+            }
+            if (strip.size() > want) strip.resize(want);
+        } else {
+            strip.resize(want);
+            size_t got = want;
+            if (!inflate_into(src, counts[s], strip.data(), &got)) throw Fail{MARAY_E_DECODE, "bad TIFF Deflate data"};
+            strip.resize(got);
+        }
+        if (strip.size() < want) throw Fail{MARAY_E_DECODE, "TIFF strip decodes to fewer bytes than its rows"};
+        for (uint32_t r = 0; r < rows; r++) {
+            uint8_t *line = strip.data() + (size_t)r * row_bytes;
+            if (predictor == 2) {                              // horizontal differencing, per sample, in the file's byte order
+                if (bps == 1) for (size_t i = spp; i < row_bytes; i++) line[i] = (uint8_t)(line[i] + line[i - spp]);
+                else for (size_t i = spp; i < (size_t)w * spp; i++) {
+                    const unsigned a = t.big ? ((unsigned)line[2 * i] << 8) | line[2 * i + 1] : le16(&line[2 * i]);
+                    const unsigned p = t.big ? ((unsigned)line[2 * (i - spp)] << 8) | line[2 * (i - spp) + 1] : le16(&line[2 * (i - spp)]);
+                    const unsigned v = (a + p) & 0xFFFFu;
+                    if (t.big) { line[2 * i] = (uint8_t)(v >> 8); line[2 * i + 1] = (uint8_t)v; } else { line[2 * i] = (uint8_t)v; line[2 * i + 1] = (uint8_t)(v >> 8); }
+                }
+            }
+            uint8_t *dst = out.p + ((size_t)(s * rps + r) * w) * 3;
+            for (uint32_t x = 0; x < w; x++) {
+                unsigned v[3];
+                for (uint32_t k = 0; k < colour; k++) {
+                    const uint8_t *q = line + ((size_t)x * spp + k) * bps;
+                    unsigned u = bps == 1 ? q[0] : (t.big ? ((unsigned)q[0] << 8) | q[1] : le16(q));
+                    if (photo == 0) u = (bps == 1 ? 255u : 65535u) - u;          // WhiteIsZero
+                    v[k] = bps == 1 ? u : to8(u);
+                }
+                dst[3 * x] = (uint8_t)v[0]; dst[3 * x + 1] = (uint8_t)v[colour == 3 ? 1 : 0]; dst[3 * x + 2] = (uint8_t)v[colour == 3 ? 2 : 0];
+            }
+        }
+    }
+}
+
 bool ends_with(const char *s, const char *suffix)
 {
     const size_t n = strlen(s), m = strlen(suffix);
@@ -387,9 +548,9 @@ extern "C" int maray_image_read(const char *path, uint8_t **rgb8_out, uint32_t *
         else if (b.size() >= 3 && b[0] == 0xFF && b[1] == 0xD8 && b[2] == 0xFF) throw Fail{MARAY_E_DECODE, "JPEG textures are not supported: convert the file to PNG"};
         else if (b.size() >= 6 && (!memcmp(b.data(), "GIF87a", 6) || !memcmp(b.data(), "GIF89a", 6))) gif(b, out, w, h);
         else if (b.size() >= 12 && !memcmp(b.data(), "RIFF", 4) && !memcmp(&b[8], "WEBP", 4)) throw Fail{MARAY_E_DECODE, "WebP textures are not supported: convert the file to PNG"};
-        else if (b.size() >= 4 && (!memcmp(b.data(), "II*\0", 4) || !memcmp(b.data(), "MM\0*", 4))) throw Fail{MARAY_E_DECODE, "TIFF textures are not supported: convert the file to PNG"};
+        else if (b.size() >= 8 && (!memcmp(b.data(), "II*\0", 4) || !memcmp(b.data(), "MM\0*", 4))) tiff(b, out, w, h);
         else if (ends_with(path, ".tga") || (b.size() >= 26 && !memcmp(&b[b.size() - 18], "TRUEVISION-XFILE", 16))) tga(b, out, w, h);       // TGA has no signature up front
-        else throw Fail{MARAY_E_DECODE, "texture file format not recognised (PNG, BMP, PNM, TGA, QOI, farbfeld and GIF are read)"};
+        else throw Fail{MARAY_E_DECODE, "texture file format not recognised (PNG, BMP, PNM, TGA, QOI, farbfeld, GIF and TIFF are read)"};
         *rgb8_out = out.release(); *w_out = w; *h_out = h;
         return MARAY_OK;
     }

@@ -1,5 +1,5 @@
 """Texture files: `image::open(file).to_rgb8()` (/root/reference/examples/maray.rs:58-65) takes whatever the `image` crate
-knows; maray_image_read takes PNG (every colour type and depth, interlaced too), BMP, PNM, TGA, QOI, farbfeld and GIF, told from
+knows; maray_image_read takes PNG (every colour type and depth, interlaced too), BMP, PNM, TGA, QOI, farbfeld, GIF and TIFF, told from
 the file's first bytes, and names the codecs it does not restate.  Reference decodings: Pillow, and the formats' own
 definitions where Pillow has no writer."""
 import os
@@ -222,10 +222,93 @@ def test_gif(tmp_path):
         assert e.value.code == -3, (name, str(e.value))
 
 
+def _tiff(big, w, h, fields, strips):
+    """A TIFF by hand: header, the strips' bytes, then one IFD of SHORT / LONG fields {tag: value or list}; StripOffsets and
+    StripByteCounts are filled in."""
+    E = '>' if big else '<'
+    body = b''.join(strips)
+    offs, at = [], 8
+    for st in strips:
+        offs.append(at)
+        at += len(st)
+    fields = dict(fields)
+    fields.update({256: w, 257: h, 273: offs, 279: [len(st) for st in strips]})
+    ifd_at = 8 + len(body) + (len(body) & 1)
+    entries, extra = [], b''
+    extra_at = ifd_at + 2 + 12 * len(fields) + 4
+    for tag in sorted(fields):
+        v = fields[tag] if isinstance(fields[tag], list) else [fields[tag]]
+        typ = 4 if tag in (273, 279) or max(v) > 65535 else 3
+        raw = b''.join(struct.pack(E + ('I' if typ == 4 else 'H'), x) for x in v)
+        if len(raw) <= 4:
+            entries.append(struct.pack(E + 'HHI', tag, typ, len(v)) + raw.ljust(4, b'\0'))
+        else:
+            entries.append(struct.pack(E + 'HHII', tag, typ, len(v), extra_at + len(extra)))
+            extra += raw + (b'\0' if len(raw) & 1 else b'')
+    return ((b'MM\0*' if big else b'II*\0') + struct.pack(E + 'I', ifd_at) + body + (b'\0' if len(body) & 1 else b'') +
+            struct.pack(E + 'H', len(entries)) + b''.join(entries) + struct.pack(E + 'I', 0) + extra)
+
+
+def test_tiff(tmp_path, pic):
+    """TIFF: grey and RGB strips of 8 or 16 bits, either byte order, uncompressed / LZW / Deflate / PackBits, horizontal
+    differencing, extra samples dropped, WhiteIsZero inverted -- as `image`'s TiffDecoder + to_rgb8 give them; tiles,
+    palettes and other sample widths are named and refused."""
+    im = Image.fromarray(pic)
+    for name, kw in (('raw', {}), ('lzw', {'compression': 'tiff_lzw'}), ('deflate', {'compression': 'tiff_adobe_deflate'}),
+                     ('packbits', {'compression': 'packbits'}), ('lzw_pred', {'compression': 'tiff_lzw', 'tiffinfo': {317: 2}}),
+                     ('strips', {'tiffinfo': {278: 5}})):
+        p = str(tmp_path / (name + '.tif'))
+        im.save(p, **kw)
+        assert np.array_equal(M.image_read(p), pic), name
+    p = str(tmp_path / 'rgba.tif')
+    im.convert('RGBA').save(p)
+    assert np.array_equal(M.image_read(p), pic)
+    grey = np.asarray(im.convert('L'))
+    p = str(tmp_path / 'grey.tif')
+    im.convert('L').save(p, compression='tiff_lzw')
+    assert np.array_equal(M.image_read(p), np.repeat(grey[:, :, None], 3, axis=2))
+    rng = np.random.default_rng(8)
+    g16 = rng.integers(0, 65536, (20, 31), dtype=np.uint16)
+    p = str(tmp_path / 'grey16.tif')
+    Image.fromarray(g16).save(p)
+    assert np.array_equal(M.image_read(p)[:, :, 0], ((g16.astype(np.uint32) * 255 + 32767) // 65535).astype(np.uint8))
+    big = rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)
+    big[:, :200] = big[0, 0]
+    p = str(tmp_path / 'big.tif')
+    Image.fromarray(big).save(p, compression='tiff_lzw')                 # the code table fills and is cleared
+    assert np.array_equal(M.image_read(p), big)
+    # by hand: big-endian RGB of 16 bits with horizontal differencing in two strips; little-endian WhiteIsZero grey
+    v = rng.integers(0, 65536, (5, 7, 3), dtype=np.uint16)
+    d = v.astype(np.int64).copy()
+    d[:, 1:] = (v[:, 1:].astype(np.int64) - v[:, :-1]) & 0xFFFF
+    rows = [d[y].astype('>u2').tobytes() for y in range(5)]
+    want16 = ((v.astype(np.uint32) * 255 + 32767) // 65535).astype(np.uint8)
+    p = str(tmp_path / 'be16.tif')
+    open(p, 'wb').write(_tiff(True, 7, 5, {258: [16, 16, 16], 259: 1, 262: 2, 277: 3, 278: 3, 317: 2}, [b''.join(rows[:3]), b''.join(rows[3:])]))
+    assert np.array_equal(M.image_read(p), want16)
+    w0 = rng.integers(0, 256, (4, 6), dtype=np.uint8)
+    p = str(tmp_path / 'white0.tif')
+    open(p, 'wb').write(_tiff(False, 6, 4, {258: 8, 259: 1, 262: 0, 277: 1, 278: 4}, [w0.tobytes()]))
+    assert np.array_equal(M.image_read(p)[:, :, 1], 255 - w0)
+    # refused or broken
+    raw = pic[:4, :6].tobytes()
+    ok = {258: [8, 8, 8], 259: 1, 262: 2, 277: 3, 278: 4}
+    bad = {'tiled.tif': _tiff(False, 6, 4, {**ok, 322: 16, 323: 16}, [raw]), 'palette.tif': _tiff(False, 6, 4, {258: 8, 259: 1, 262: 3, 277: 1, 278: 4}, [bytes(24)]),
+           'bits4.tif': _tiff(False, 6, 4, {258: 4, 259: 1, 262: 1, 277: 1, 278: 4}, [bytes(12)]), 'short.tif': _tiff(False, 6, 4, ok, [raw[:40]]),
+           'comp.tif': _tiff(False, 6, 4, {**ok, 259: 7}, [raw]), 'huge.tif': _tiff(False, 1 << 20, 1 << 20, ok, [raw]),
+           'lzw.tif': _tiff(False, 6, 4, {**ok, 259: 5}, [bytes([0x80, 0x3F, 0xFF, 0xFF])]), 'trunc.tif': _tiff(False, 6, 4, ok, [raw])[:60]}
+    for name, data in bad.items():
+        p = str(tmp_path / name)
+        open(p, 'wb').write(data)
+        with pytest.raises(M.MarayError) as e:
+            M.image_read(p)
+        assert e.value.code in (-3, -7), (name, str(e.value))
+
+
 def test_formats_not_restated_and_broken_files_are_errors(tmp_path, pic):
     Image.fromarray(pic).save(str(tmp_path / 'a.jpg'))
-    Image.fromarray(pic).save(str(tmp_path / 'a.tif'))
-    for name, word in (('a.jpg', 'JPEG'), ('a.tif', 'TIFF')):
+    Image.fromarray(pic).save(str(tmp_path / 'a.webp'), lossless=True)
+    for name, word in (('a.jpg', 'JPEG'), ('a.webp', 'WebP')):
         with pytest.raises(M.MarayError) as e:
             M.image_read(str(tmp_path / name))
         assert e.value.code == -3 and word in str(e.value) and 'convert' in str(e.value)

@@ -130,6 +130,27 @@ def test_image_readers_with_crafted_headers_under_asan_ubsan(tmp_path):
         'qoi_huge.qoi': b'qoif' + struct.pack('>IIBB', 0xFFFFFFFF, 0xFFFFFFFF, 4, 0) + bytes(16),
         'ff_short.ff': b'farbfeld' + struct.pack('>II', 100, 100) + bytes(64), 'ff_huge.ff': b'farbfeld' + struct.pack('>II', 0xFFFFFFFF, 2),
     }
+    # TIFF: Pillow's files in every compression, then truncated, with fields pointing outside the file, with sizes that lie
+    for name, kw in (('good_raw.tif', {}), ('good_lzw.tif', {'compression': 'tiff_lzw', 'tiffinfo': {317: 2}}), ('good_zip.tif', {'compression': 'tiff_adobe_deflate'}),
+                     ('good_pb.tif', {'compression': 'packbits'})):
+        p = str(tmp_path / name)
+        im.save(p, **kw)
+        paths.append(p)
+        t = open(p, 'rb').read()
+        stem = name[5:-4]
+        files['tif_%s_half.tif' % stem] = t[:len(t) // 2]
+        files['tif_%s_tail.tif' % stem] = t[:-9]
+        files['tif_%s_ifd.tif' % stem] = t[:4] + struct.pack('<I', len(t) - 3) + t[8:]
+        k = t.find(struct.pack('<HHI', 256, 3, 1))                         # ImageWidth SHORT 1
+        if k >= 0:
+            files['tif_%s_wide.tif' % stem] = t[:k + 8] + struct.pack('<HH', 60000, 0) + t[k + 12:]
+        k = t.find(struct.pack('<HH', 273, 4))                             # StripOffsets LONG
+        if k >= 0:
+            files['tif_%s_off.tif' % stem] = t[:k + 8] + struct.pack('<I', 0xFFFFFF00) + t[k + 12:]
+        k = t.find(struct.pack('<HH', 279, 4))                             # StripByteCounts LONG
+        if k >= 0:
+            files['tif_%s_cnt.tif' % stem] = t[:k + 8] + struct.pack('<I', 0x7FFFFFFF) + t[k + 12:]
+    files['tif_lzw_noise.tif'] = open(str(tmp_path / 'good_lzw.tif'), 'rb').read()[:8] + bytes(rng.integers(0, 256, 300, dtype=np.uint8)) + open(str(tmp_path / 'good_lzw.tif'), 'rb').read()[308:]
     # GIF: Pillow's files, and the same with bytes knocked out / the header lying / random LZW data
     for name, kw in (('good_a.gif', {}), ('good_i.gif', {'interlace': True})):
         p = str(tmp_path / name)
