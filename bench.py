@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — Mpixels/s of the MI355X evaluator on chess.maray @ 4096x4096.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
-is launched under torch.distributed.run with one rank per GPU.  A "step" is one
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  For N > 1 it
+runs one rank per GPU: under torch.distributed.run when the driver starts it that
+way (WORLD_SIZE set), else it starts its own N ranks as child processes and
+relays rank 0's line (the parent never touches HIP).  With fewer visible GPUs
+than ranks the ranks share them (a rehearsal, said so in the line).  A "step" is one
 pass of the hot path over the rank's share (4096 x 4096 pixels) of one image of
 the chess scene, outputs resident in HBM.  Pixels are independent, so ranks own
 disjoint rows (interleaved 64-row blocks, for balance) and no data-path
@@ -88,24 +91,59 @@ def main():
     ap.add_argument('--no-cpu-jit', action='store_true', help='skip the JIT stand-in (B2)')
     ap.add_argument('--no-cold', action='store_true', help='skip the cold / warm first-render measurement')
     ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end (host raster) measurement')
+    ap.add_argument('--long-steps', type=int, default=2000, help='steps of the long loop between two fences (0 = skip)')
+    ap.add_argument('--rank-timeout', type=float, default=1500.0, help='seconds the launcher waits for its ranks')
     args = ap.parse_args()
+
+    fake_world = os.environ.get('MARAY_BENCH_FAKE_WORLD')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and not fake_world:
+        # `python bench.py --gpus N` with no launcher around it: this process becomes the launcher.  It has imported
+        # neither torch nor the library and never touches HIP; the ranks are fresh children (never an exec), one per
+        # GPU, environment as torch.distributed.run sets it.  Rank 0's JSON line is relayed; any rank's failure is ours.
+        from maray_amd.sharding import launch_ranks
+        rc, out = launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, timeout=args.rank_timeout)
+        lines = [ln for ln in out.splitlines() if ln.startswith('{')]
+        for ln in out.splitlines():
+            if not ln.startswith('{'):
+                print(ln, file=sys.stderr)
+        if lines:
+            print(lines[-1], flush=True)
+        elif rc == 0:
+            rc = 1
+        if rc != 0:
+            print('bench.py: the %d-rank run failed (exit code %d)' % (args.gpus, rc), file=sys.stderr)
+        raise SystemExit(rc)
 
     import torch
     import torch.distributed as dist
 
     import maray_amd as M
+    from maray_amd.sharding import device_of_rank
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not fake_world and args.gpus != world:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` (it launches its own '
+                         'ranks) or under torch.distributed.run with --nproc-per-node N' % (args.gpus, world))
+    n_dev = torch.cuda.device_count()          # counting devices does not initialise HIP
+    if n_dev == 0:
+        raise SystemExit('bench.py needs a MI355X: no HIP device is visible (there is no CPU fallback)')
+    device, rehearsal = device_of_rank(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)), n_dev)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        # one rank per GPU: RCCL.  Fewer GPUs than ranks (a rehearsal on a one-GPU lease): the ranks share the devices and
+        # the timing barrier / max go through gloo, RCCL refuses two ranks on one device.  No data-path collective either way.
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', device))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a MI355X: no HIP device is visible (there is no CPU fallback)')
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(device)
+    red_dev = None if rehearsal else 'cuda'   # where the max-over-ranks tensor lives
     n_gpus = world
-    if world == 1 and os.environ.get('MARAY_BENCH_FAKE_WORLD'):      # rehearse rank r of N on one GPU, no process group
-        n_gpus = int(os.environ['MARAY_BENCH_FAKE_WORLD'])
+    if world == 1 and fake_world:      # rehearse rank r of N on one GPU, no process group
+        n_gpus = int(fake_world)
         rank = int(os.environ.get('MARAY_BENCH_FAKE_RANK', '0'))
     solo = rank == 0 and n_gpus == 1 and world == 1
 
@@ -146,7 +184,7 @@ def main():
     t_ctx0 = time.perf_counter()
     for name in order:
         try:
-            ctx = M.Context(tape, device=local, backend=backends[name])
+            ctx = M.Context(tape, device=device, backend=backends[name])
             backend_name = name
             break
         except M.MarayError as e:
@@ -192,10 +230,47 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    dt = max_over_ranks(dist if world > 1 else None, dt, device='cuda')
+    dt = max_over_ranks(dist if world > 1 else None, dt, device=red_dev)
 
     px_per_step = w_img * h_total
     value = px_per_step * args.steps / dt / 1e6
+
+    # the same step frame after frame for long enough that one fence is < 0.1 % of the region and a once-a-second utilisation
+    # sampler sees the GPU busy: `value` above is --steps steps between two fences, i.e. 0.7 ms at the driver's 20 x 36 us
+    long_loop = None
+    if args.long_steps > 0:
+        fence()
+        t = time.perf_counter()
+        for _ in range(args.long_steps):
+            step()
+        fence()
+        dtl = max_over_ranks(dist if world > 1 else None, time.perf_counter() - t, device=red_dev)
+        long_loop = {'value': px_per_step * args.long_steps / dtl / 1e6, 'unit': 'Mpixels/s', 'steps': args.long_steps,
+                     'ms_per_step': dtl / args.long_steps * 1e3, 'seconds': dtl,
+                     'what': 'the timed step, %d times between two fences (barrier + synchronize, max over ranks)' % args.long_steps}
+
+    # what this box's HBM takes when nothing is computed: hipMemsetAsync over this rank's raster on the launch stream (the
+    # fill the runtime itself issues; profiles/r3_store_floor.json has hand-written stores of several widths beside it)
+    attainable = None
+    try:
+        import ctypes
+        hip = ctypes.CDLL('libamdhip64.so')
+        hip.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+        nbytes = out8.numel()
+        for _ in range(5):
+            hip.hipMemsetAsync(out8.data_ptr(), 0, nbytes, stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 100
+        e0.record()
+        for _ in range(reps):
+            hip.hipMemsetAsync(out8.data_ptr(), 0, nbytes, stream)
+        e1.record()
+        e1.synchronize()
+        fill_ms = e0.elapsed_time(e1) / reps
+        attainable = {'value': nbytes / (fill_ms * 1e-3) / 1e9, 'unit': 'GB/s', 'ms': fill_ms, 'bytes': nbytes,
+                      'source': 'hipMemsetAsync of this raster, %d in a row on the launch stream, in this run' % reps}
+    except (OSError, AttributeError) as e:
+        attainable = {'error': str(e)}
 
     # roofline of the dominant (pixel) kernel: HIP events on the launch stream, around the very launch a step issues (this
     # rank's whole share; its first block when the share is ragged and goes block by block)
@@ -241,7 +316,7 @@ def main():
             t = time.perf_counter()
             ctx.render_tiles(w_img, h_total, tiles, pin.array)
             times.append(time.perf_counter() - t)
-        t_med = max_over_ranks(dist if world > 1 else None, statistics.median(times), device='cuda')
+        t_med = max_over_ranks(dist if world > 1 else None, statistics.median(times), device=red_dev)
         same = None
         if rank == 0 and n_gpus == 1:
             same = bool(np.array_equal(pin.array, out8.cpu().numpy()))
@@ -297,7 +372,7 @@ def main():
     traffic = None
     executed = None
     traffic_profile = None
-    for rnd in ('r3', 'r2', 'r1'):
+    for rnd in ('r4', 'r3', 'r2', 'r1'):
         prof = os.path.join(ROOT, 'profiles', '%s_%s_chess4096_pmc.json' % (rnd, backend_name))
         if not os.path.exists(prof):
             continue
@@ -325,7 +400,7 @@ def main():
         sc4 = M.Scene(data)
         sc4.rescale(16, 16)
         t4 = sc4.lower()
-        c4 = M.Context(t4, device=local, backend=backends[backend_name])
+        c4 = M.Context(t4, device=device, backend=backends[backend_name])
         lay4 = interleaved_layout(rank, n_gpus, 16384, BLOCK_ROWS)
         blk4 = interleaved_blocks(rank, n_gpus, 16384, BLOCK_ROWS)
         rows4 = sum(b - a for a, b in blk4)
@@ -346,7 +421,7 @@ def main():
         for _ in range(args.steps):
             step4()
         fence()
-        dt4 = max_over_ranks(dist if world > 1 else None, time.perf_counter() - t, device='cuda')
+        dt4 = max_over_ranks(dist if world > 1 else None, time.perf_counter() - t, device=red_dev)
         ok4 = None
         if rank == 0:       # rank 0's first row is stored row 0
             ok4 = hashlib.sha256(buf4[0, ::16].contiguous().cpu().numpy().tobytes()).hexdigest() == golden['row_sha256']['0']
@@ -410,6 +485,8 @@ def main():
                        'bit_exact_vs_golden': parity, 'code_key': tape.jit_code_key if backend_name == 'jit' else None},
             'roofline': {'bound': 'hbm', 'achieved': hbm_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                          'frac': hbm_gbs / PEAK_HBM_GBS, 'traffic': traffic, 'traffic_profile': traffic_profile,
+                         'attainable_peak': attainable,
+                         'frac_of_attainable': (hbm_gbs / attainable['value']) if attainable and attainable.get('value') else None,
                          'kernel_ms': k_ms, 'alg_bytes_per_pixel': 3, 'pixels_per_launch': px_launch,
                          'note': 'achieved = 3 B/pixel (SURVEY 8(d): the RGB8 pixel written is the only mandatory HBM '
                                  'traffic) x pixels of one launch / its HIP-event time; traffic = FETCH_SIZE x2 + WRITE_SIZE '
@@ -421,6 +498,10 @@ def main():
                                                      'proves 0 over a rectangle of 64 x 32 pixels are skipped, and half of what remains is '
                                                      'boolean algebra on lane masks (scalar unit)'},
                          'executed': executed},
+            'long_loop': long_loop,
+            'rehearsal': ('%d ranks share %d visible device(s): sharding, launches and timing discipline are the real ones, '
+                          'the ranks queue for one GPU, so this is not a scaling figure (gloo for the barrier / max)' % (world, n_dev))
+                         if rehearsal else None,
             'end_to_end': e2e,
             'config4_strong': config4,
             'cold_first_render_ms': cold,

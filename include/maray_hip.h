@@ -260,6 +260,10 @@ int maray_gen_to_image(const maray_scene *s, const maray_texture *tex, uint32_t 
  * same scene, textures and back-end (the last MARAY_GEN_CACHE programs, default 4, 0 = none): an animation that calls
  * it in a loop (examples/test*.rs) pays the lowering and the context creation once, not per frame.  This frees them. */
 void maray_gen_cache_clear(void);
+/* What is kept, one line per idle context: "<program key> device <d> kernel <name> hint_mpixels <n>" (NUL-terminated,
+ * cut to cap).  Under MARAY_BACKEND_AUTO a kept interpreter context is replaced when a later call renders more than
+ * the call it was chosen for; contexts are kept per physical device. */
+int maray_gen_cache_info(char *out, size_t cap);
 /* gen: render and write a PNG (progress callback prints "%.2f %%" to stderr
  * and re-saves the partial image, like src/lib.rs:1203-1208). */
 int maray_gen(const maray_scene *s, const maray_texture *tex, uint32_t n_tex,

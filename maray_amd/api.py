@@ -119,6 +119,7 @@ def lib():
                                          u32, u32]),
         'maray_gen': (C.c_int, [vp, C.POINTER(Texture), u32, C.POINTER(GenOpts), Report, C.c_char_p]),
         'maray_gen_cache_clear': (None, []),
+        'maray_gen_cache_info': (C.c_int, [C.c_char_p, C.c_size_t]),
         'maray_png_write': (C.c_int, [C.c_char_p, vp, u32, u32]),
         'maray_png_read': (C.c_int, [C.c_char_p, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]),
         'maray_image_read': (C.c_int, [C.c_char_p, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]),
@@ -415,6 +416,13 @@ def gen(scene, path, textures=None, backend=BACKEND_AUTO, n_devices=0, report_ki
 def gen_cache_clear():
     """Frees the tapes and contexts maray_gen_to_image keeps between calls."""
     lib().maray_gen_cache_clear()
+
+
+def gen_cache_info():
+    """One line per idle context maray_gen_to_image keeps: program key, device, kernel, the size it was chosen for."""
+    buf = C.create_string_buffer(1 << 16)
+    _check(lib().maray_gen_cache_info(buf, len(buf)))
+    return buf.value.decode().splitlines()
 
 
 def png_write(path, rgb8):

@@ -85,12 +85,16 @@ int fail_with(int code, const std::string &m) { set_last_error(m); return code; 
 // scene's encoding + the textures' bytes + the back-end asked for.  The last MARAY_GEN_CACHE programs (default 4; 0: none)
 // are kept; maray_gen_cache_clear() frees them.  A context serves one call at a time: a second call for the same program
 // while the first is still rendering gets contexts of its own.
+struct IdleCtx {
+    maray_ctx *ctx = nullptr;
+    uint32_t hint_mpixels = 0;                // what MARAY_BACKEND_AUTO was told when it chose this context's evaluator (0: "many")
+};
 struct GenEntry {
     std::string key;
     maray_tape *tape = nullptr;
-    std::map<int, maray_ctx *> idle;          // per worker slot: a context nobody is rendering with
+    std::multimap<int, IdleCtx> idle;         // per PHYSICAL device: contexts nobody is rendering with
     bool evicted = false;
-    ~GenEntry() { for (auto &kv : idle) maray_hip_ctx_free(kv.second); maray_tape_free(tape); }
+    ~GenEntry() { for (auto &kv : idle) maray_hip_ctx_free(kv.second.ctx); maray_tape_free(tape); }
 };
 std::mutex g_gen_mutex;
 // most recently used first.  Never destroyed: at process exit the HIP runtime may be gone before a static's destructor
@@ -128,21 +132,34 @@ std::shared_ptr<GenEntry> gen_cache_insert(std::shared_ptr<GenEntry> fresh)
     return fresh;
 }
 
-maray_ctx *gen_cache_take(GenEntry &e, int slot)
+// A context of `dev` that an earlier call left.  Keyed by the physical device, not by the worker that used it: after a
+// call whose workers shared a device (MARAY_GEN_WRAP_DEVICES) worker 1's context lives on device 0, and a later call
+// that gives worker 1 a device of its own must not be handed it.  Under MARAY_BACKEND_AUTO a context stands for the
+// choice made for the FIRST call's size: an interpreter context taken for a thumbnail is not what a 16384^2 frame
+// wants, so a kept interpreter context is dropped (the caller makes a new one, AUTO decides again) when this call is
+// to render more than it was chosen for.
+maray_ctx *gen_cache_take(GenEntry &e, int dev, bool auto_backend, uint32_t hint_mpixels)
 {
-    std::lock_guard<std::mutex> lk(g_gen_mutex);
-    auto it = e.idle.find(slot);
-    if (it == e.idle.end()) return nullptr;
-    maray_ctx *c = it->second;
-    e.idle.erase(it);
+    maray_ctx *stale = nullptr, *c = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_gen_mutex);
+        auto it = e.idle.find(dev);
+        if (it == e.idle.end()) return nullptr;
+        const IdleCtx ic = it->second;
+        e.idle.erase(it);
+        const bool interp = strncmp(maray_hip_kernel_name(ic.ctx), "maray_jit", 9) != 0;
+        if (auto_backend && interp && ic.hint_mpixels != 0 && (hint_mpixels == 0 || hint_mpixels > ic.hint_mpixels)) stale = ic.ctx;
+        else c = ic.ctx;
+    }
+    if (stale) maray_hip_ctx_free(stale);
     return c;
 }
 
-void gen_cache_give(GenEntry &e, int slot, maray_ctx *c)
+void gen_cache_give(GenEntry &e, int dev, maray_ctx *c, uint32_t hint_mpixels)
 {
     {
         std::lock_guard<std::mutex> lk(g_gen_mutex);
-        if (!e.evicted && gen_cache_capacity() && !e.idle.count(slot)) { e.idle[slot] = c; return; }
+        if (!e.evicted && gen_cache_capacity() && e.idle.count(dev) < 4) { e.idle.insert({dev, IdleCtx{c, hint_mpixels}}); return; }
     }
     maray_hip_ctx_free(c);
 }
@@ -173,6 +190,21 @@ extern "C" void maray_gen_cache_clear(void)
         for (auto &e : g_gen) e->evicted = true;
         dead.swap(g_gen);
     }
+}
+
+extern "C" int maray_gen_cache_info(char *out, size_t cap)
+{
+    if (!out || !cap) return fail_with(MARAY_E_ARG, "null argument");
+    std::string t;
+    {
+        std::lock_guard<std::mutex> lk(g_gen_mutex);
+        for (auto &e : g_gen)
+            for (auto &kv : e->idle)
+                t += e->key + " device " + std::to_string(kv.first) + " kernel " + maray_hip_kernel_name(kv.second.ctx) + " hint_mpixels " +
+                     std::to_string(kv.second.hint_mpixels) + "\n";
+    }
+    snprintf(out, cap, "%s", t.c_str());
+    return MARAY_OK;
 }
 
 extern "C" int maray_gen_to_image(const maray_scene *s, const maray_texture *tex, uint32_t n_tex,
@@ -259,13 +291,14 @@ extern "C" int maray_gen_to_image(const maray_scene *s, const maray_texture *tex
     auto worker = [&](uint32_t d) {
         // worker d's context: the one an earlier call left (same program, same worker slot), or a new one
         const int dev = wrap ? (int)(d % (uint32_t)n_dev_avail) : (int)d;
-        maray_ctx *ctx = gen_cache_take(*entry, (int)d);
+        maray_ctx *ctx = gen_cache_take(*entry, dev, co.backend == MARAY_BACKEND_AUTO, co.hint_mpixels);
+        const bool kept = ctx != nullptr;
         int r = ctx ? MARAY_OK : maray_hip_ctx_create(dev, &prog, tex, n_tex, &co, &ctx);
         if (!r && !share[d].empty())
             r = maray_hip_render_tiles(ctx, w, h, share[d].data(), (uint32_t)(share[d].size() / 2), rgb8, on_tile, &tu);
         const std::string msg = r ? maray_last_error() : "";      // this thread's message, re-raised on the calling thread
         if (r) maray_hip_ctx_free(ctx);                           // (a context that failed is not kept)
-        else gen_cache_give(*entry, (int)d, ctx);
+        else gen_cache_give(*entry, dev, ctx, kept ? 0u : co.hint_mpixels);
         std::lock_guard<std::mutex> lk(P.m);
         if (r && !P.failed) { P.failed = r; P.err = msg; }
         P.finished++;

@@ -12,7 +12,9 @@
 // one of them is MARAY_E_DECODE with the format's name ("convert it to PNG"), not a wrong picture.
 //
 // Sizes come from the file: every product is formed in 64 bits and bounded (2^20 pixels a side, the evaluators' own
-// limit; the pixel data the header promises must be there) before anything is allocated or indexed.
+// limit), and nothing is allocated, reserved or touched before the file has been shown able to hold that much pixel
+// data in its coding (raster(): bytes present x the format's best expansion ratio; TIFF strip by strip; a GIF's blank
+// logical screen by a fixed 512 MiB budget).
 #include <zlib.h>
 
 #include <algorithm>
@@ -38,14 +40,22 @@ uint32_t le32(const uint8_t *p) { return le16(p) | (le16(p + 2) << 16); }
 uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 unsigned to8(unsigned v16) { return (v16 * 255u + 32767u) / 65535u; }        // DynamicImage::to_rgb8 on 16-bit samples
 
-uint8_t *raster(uint32_t w, uint32_t h)
+// The raster of a w x h image -- allocated only once the caller has shown that the FILE can hold that many pixels:
+// `max_px` is the most pixels its `data_bytes` of pixel data can encode in this format (data_bytes x the format's best
+// ratio), formed by the caller from the file's real size.  A header's word alone never sizes an allocation: a 40-byte
+// file that declares 65535 x 65535 pixels is MARAY_E_DECODE, not 12.9 GB of zeroed pages (the reference's image::open runs
+// under the crate's default Limits).
+uint8_t *raster(uint32_t w, uint32_t h, uint64_t max_px, bool zeroed = false)
 {
     if (!w || !h) throw Fail{MARAY_E_DECODE, "image without pixels"};
     if (w > MARAY_DOMAIN_MAX || h > MARAY_DOMAIN_MAX || (uint64_t)w * h * 3 > IMAGE_MAX_BYTES) throw Fail{MARAY_E_LIMIT, "image larger than 1048576 pixels a side"};
-    uint8_t *p = (uint8_t *)malloc((size_t)w * h * 3);
+    if ((uint64_t)w * h > max_px) throw Fail{MARAY_E_DECODE, "pixel data shorter than the header says (the file cannot hold " + std::to_string((uint64_t)w * h) + " pixels)"};
+    uint8_t *p = (uint8_t *)(zeroed ? calloc((size_t)w * h, 3) : malloc((size_t)w * h * 3));
     if (!p) throw Fail{MARAY_E_INTERNAL, "out of memory"};
     return p;
 }
+
+uint64_t sat_mul(uint64_t a, uint64_t b) { return (b && a > UINT64_MAX / b) ? UINT64_MAX : a * b; }
 
 // zlib stream -> at most *n bytes of dst; *n = what arrived (a strip's last rows may be short of the nominal size)
 bool inflate_into(const uint8_t *src, size_t src_n, uint8_t *dst, size_t *n)
@@ -75,10 +85,10 @@ void bmp(const std::vector<uint8_t> &b, Owned &out, uint32_t &w, uint32_t &h)
     if (!(comp == 0 || (comp == 3 && (bpp == 32 || bpp == 16)))) throw Fail{MARAY_E_DECODE, "compressed BMP is not supported"};
     if (!(bpp == 8 || bpp == 24 || bpp == 32)) throw Fail{MARAY_E_DECODE, "BMP bit depth not supported (8, 24 and 32 are)"};
     w = (uint32_t)sw; h = (uint32_t)(sh < 0 ? -sh : sh);
-    out.p = raster(w, h);
     const uint64_t stride = (((uint64_t)w * bpp + 31) / 32) * 4;
     if ((uint64_t)off + stride * h > b.size()) throw Fail{MARAY_E_DECODE, "BMP pixel data shorter than its header says"};
     if ((uint64_t)14 + hdr > b.size()) throw Fail{MARAY_E_DECODE, "BMP header longer than the file"};
+    out.p = raster(w, h, (uint64_t)b.size());                    // (a pixel is at least a byte)
     const uint8_t *pal = b.data() + 14 + hdr;
     uint32_t ncol = le32(&b[46]);
     if (bpp == 8) {
@@ -119,7 +129,8 @@ void pnm(const std::vector<uint8_t> &b, Owned &out, uint32_t &w, uint32_t &h)
     w = number(); h = number();
     const uint32_t maxv = (kind == 1 || kind == 4) ? 1u : number();
     if (!maxv || maxv > 65535) throw Fail{MARAY_E_DECODE, "bad PNM maxval"};
-    out.p = raster(w, h);
+    // plain forms: a sample is at least a digit (P1) or a digit and a separator; raw: P4 packs 8 pixels a byte
+    out.p = raster(w, h, sat_mul(b.size() - std::min(pos, b.size()) + 1, kind == 4 ? 8 : 1));
     const int ch = (kind == 3 || kind == 6) ? 3 : 1;
     auto scale = [&](uint32_t v) -> uint8_t {        // image's PNM decoder yields 8- or 16-bit samples scaled to the full range
         if (v > maxv) v = maxv;
@@ -172,17 +183,18 @@ void tga(const std::vector<uint8_t> &b, Owned &out, uint32_t &w, uint32_t &h)
     if (base == 1 && (cmtype != 1 || !(cmbits == 24 || cmbits == 32) || bpp != 8)) throw Fail{MARAY_E_DECODE, "TGA colour map not supported"};
     if (base == 2 && !(bpp == 24 || bpp == 32)) throw Fail{MARAY_E_DECODE, "TGA pixel depth not supported (24 and 32 are)"};
     if (base == 3 && !(bpp == 8 || bpp == 16)) throw Fail{MARAY_E_DECODE, "TGA grey depth not supported"};
-    out.p = raster(w, h);
     size_t pos = 18 + idlen;
     const size_t cmap = pos, cmbytes = cmtype ? (size_t)cmlen * ((cmbits + 7) / 8) : 0;
     pos += cmbytes;
     if (pos > b.size()) throw Fail{MARAY_E_DECODE, "truncated TGA colour map"};
     const size_t pb = bpp / 8;
     const uint64_t npx = (uint64_t)w * h;
+    // a run-length packet of 1 + pb bytes gives up to 128 pixels; raw data a pixel per pb bytes
+    out.p = raster(w, h, (type & 8u) ? sat_mul((b.size() - pos) / (1 + pb) + 1, 128) : (b.size() - pos) / pb);
     std::vector<uint8_t> px;
     if (type & 8u) {                                   // run-length packets: 1 header byte, then one pixel (run) or n (raw)
         if (npx * pb > IMAGE_MAX_BYTES) throw Fail{MARAY_E_LIMIT, "TGA too large"};
-        px.reserve((size_t)(npx * pb));
+        px.reserve((size_t)(npx * pb));                // (<= 128 pb / (1 + pb) x the file, by the bound above)
         while (px.size() < npx * pb) {
             if (pos >= b.size()) throw Fail{MARAY_E_DECODE, "truncated TGA packet"};
             const unsigned n = (b[pos] & 0x7Fu) + 1, run = b[pos] & 0x80u;
@@ -218,7 +230,7 @@ void qoi(const std::vector<uint8_t> &b, Owned &out, uint32_t &w, uint32_t &h)
     if (b.size() < 14 + 8) throw Fail{MARAY_E_DECODE, "truncated QOI file"};
     w = be32(&b[4]); h = be32(&b[8]);
     if (!(b[12] == 3 || b[12] == 4)) throw Fail{MARAY_E_DECODE, "bad QOI channel count"};
-    out.p = raster(w, h);
+    out.p = raster(w, h, sat_mul(b.size() - 14 - 8 + 1, 62));      // QOI_OP_RUN: one byte, up to 62 pixels
     uint8_t idx[64][4];
     memset(idx, 0, sizeof idx);
     uint8_t px[4] = {0, 0, 0, 255};
@@ -253,8 +265,8 @@ void farbfeld(const std::vector<uint8_t> &b, Owned &out, uint32_t &w, uint32_t &
 {
     if (b.size() < 16) throw Fail{MARAY_E_DECODE, "truncated farbfeld header"};
     w = be32(&b[8]); h = be32(&b[12]);
-    out.p = raster(w, h);
-    if (16 + (uint64_t)w * h * 8 > b.size()) throw Fail{MARAY_E_DECODE, "farbfeld pixel data shorter than its header says"};
+    if ((uint64_t)w * h > (b.size() - 16) / 8) throw Fail{MARAY_E_DECODE, "farbfeld pixel data shorter than its header says"};
+    out.p = raster(w, h, (b.size() - 16) / 8);
     for (size_t i = 0; i < (size_t)w * h; i++)
         for (int k = 0; k < 3; k++) out.p[i * 3 + k] = (uint8_t)to8(((unsigned)b[16 + i * 8 + 2 * k] << 8) | b[16 + i * 8 + 2 * k + 1]);
 }
@@ -309,11 +321,16 @@ void gif(const std::vector<uint8_t> &b, Owned &out, uint32_t &w, uint32_t &h)
     }
     if (!pal) throw Fail{MARAY_E_DECODE, "GIF frame without a colour table"};
     if (!fw || !fh || (uint64_t)fl + fw > w || (uint64_t)ft + fh > h) throw Fail{MARAY_E_DECODE, "GIF frame outside its logical screen"};
-    out.p = raster(w, h);
-    memset(out.p, 0, (size_t)w * h * 3);
     if (pos >= b.size()) throw Fail{MARAY_E_DECODE, "truncated GIF image data"};
     const unsigned min_size = b[pos++];
     if (min_size < 1 || min_size > 11) throw Fail{MARAY_E_DECODE, "bad GIF code size"};      // (the gif crate rejects > 11 as well)
+    // What the data can paint: a code of at most 12 bits stands for a string of at most 4,095 pixels, so the frame's pixels
+    // are bounded by the bytes left (x 2,730); the logical screen around the frame is blank and costs the file nothing, so
+    // it is bounded by a fixed budget instead -- 512 MiB of raster, the `image` crate's default Limits::max_alloc -- and
+    // comes from calloc (untouched zero pages), not from a memset.
+    if ((uint64_t)fw * fh > sat_mul(b.size() - pos + 1, 2730)) throw Fail{MARAY_E_DECODE, "GIF image data shorter than its frame"};
+    if ((uint64_t)w * h * 3 > (512ull << 20)) throw Fail{MARAY_E_LIMIT, "GIF logical screen larger than 512 MiB of pixels"};
+    out.p = raster(w, h, UINT64_MAX, true);
     const unsigned clear = 1u << min_size, stop = clear + 1;
     std::vector<uint16_t> prefix(4096);
     std::vector<uint8_t> suffix(4096), first(4096), stack(4097);
@@ -464,12 +481,23 @@ void tiff(const std::vector<uint8_t> &b, Owned &out, uint32_t &w, uint32_t &h)
     if (spp < colour || spp > 8 || (planar != 1 && spp > 1)) throw Fail{MARAY_E_DECODE, "unsupported TIFF sample layout"};
     if (predictor != 1 && predictor != 2) throw Fail{MARAY_E_DECODE, "unsupported TIFF predictor"};
     if (comp != 1 && comp != 5 && comp != 8 && comp != 32946 && comp != 32773) throw Fail{MARAY_E_DECODE, "unsupported TIFF compression: convert the file to PNG"};
-    out.p = raster(w, h);
+    if (!w || !h) throw Fail{MARAY_E_DECODE, "image without pixels"};
+    if (w > MARAY_DOMAIN_MAX || h > MARAY_DOMAIN_MAX) throw Fail{MARAY_E_LIMIT, "image larger than 1048576 pixels a side"};
     if (!rps) throw Fail{MARAY_E_DECODE, "bad TIFF RowsPerStrip"};
     rps = std::min(rps, h);
     const uint32_t n_strips = (h + rps - 1) / rps;
     if (offsets.size() < n_strips || counts.size() < n_strips) throw Fail{MARAY_E_DECODE, "TIFF strip table shorter than the image"};
     const size_t bps = bits / 8, row_bytes = (size_t)w * spp * bps;
+    // Every strip must be able to hold its rows before anything is sized by them: stored bytes x the coding's best ratio
+    // (Deflate 1,032 : 1 -- 1,040 with margin, as png.cpp bounds IDAT; LZW: a 12-bit code for at most 4,095 bytes; PackBits:
+    // 2 bytes for 128).  The raster then is at most 3 x the sum of what the strips can decode to.
+    const uint64_t ratio = comp == 1 ? 1 : comp == 5 ? 2730 : comp == 32773 ? 64 : 1040;
+    for (uint32_t s = 0; s < n_strips; s++) {
+        if ((uint64_t)offsets[s] + counts[s] > b.size()) throw Fail{MARAY_E_DECODE, "TIFF strip outside the file"};
+        const uint64_t want = (uint64_t)row_bytes * std::min(rps, h - s * rps);
+        if (want > sat_mul((uint64_t)counts[s] + 1, ratio)) throw Fail{MARAY_E_DECODE, "TIFF strip too short for its rows"};
+    }
+    out.p = raster(w, h, UINT64_MAX);          // (w h spp bps = the strips' rows <= ratio x (file + strips), checked above)
     std::vector<uint8_t> strip;
     for (uint32_t s = 0; s < n_strips; s++) {
         const uint32_t rows = std::min(rps, h - s * rps);

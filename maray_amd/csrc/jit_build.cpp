@@ -43,17 +43,29 @@ namespace maray {
             throw Error{MARAY_E_HIP, std::string(#expr) + ": " + hiprtcGetErrorString(r_)};         \
     } while (0)
 
+// The compiler's options, in ONE place: JIT_OPTIONS (jit_parts.hpp, the string that goes into the code key) split into
+// words, its -O level replaced by MARAY_JIT_OPT ("-O1" builds faster: 1.7 against 2.6 s for chess, kernel 37.4 against
+// 35.6 us), MARAY_JIT_EXTRA ("-mllvm -some-flag ...", a measurement knob) appended.  The in-process compile below and the
+// helper processes (which get these very words on their command line) build with exactly what the key was made from.
+std::vector<std::string> jit_option_words()
+{
+    std::vector<std::string> out;
+    const char *olevel = getenv("MARAY_JIT_OPT");
+    std::istringstream in(JIT_OPTIONS);
+    for (std::string w; in >> w;) out.push_back((w.size() == 3 && w[0] == '-' && w[1] == 'O' && olevel && olevel[0] == '-') ? std::string(olevel) : w);
+    if (const char *e_ = getenv("MARAY_JIT_EXTRA")) { std::istringstream ex(e_); for (std::string w; ex >> w;) out.push_back(w); }
+    return out;
+}
+
 void jit_compile(const std::string &src, std::vector<char> &code, std::string &log)
 {
     hiprtcProgram prog;
     const char *headers[] = {maray_embedded_device_math_h, maray_embedded_libm_h, maray_embedded_libm_tables_h};
     const char *names[] = {"device_math.h", "maray_libm.h", "maray_libm_tables.h"};
     RTC_TRY(hiprtcCreateProgram(&prog, src.c_str(), "maray_jit.hip", 3, headers, names));
-    const char *olevel = getenv("MARAY_JIT_OPT");          // "-O1" builds faster (1.7 against 2.6 s for chess, kernel 37.4 against 35.6 us)
-    std::vector<const char *> opts = {"--offload-arch=gfx950", (olevel && olevel[0] == '-') ? olevel : "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-mllvm", "-structurizecfg-skip-uniform-regions"};
-    std::vector<std::string> extra;                        // MARAY_JIT_EXTRA="-mllvm -some-flag ...": measurement knob
-    if (const char *e_ = getenv("MARAY_JIT_EXTRA")) { std::istringstream in(e_); for (std::string w; in >> w;) extra.push_back(w); }
-    for (const std::string &w : extra) opts.push_back(w.c_str());
+    const std::vector<std::string> words = jit_option_words();
+    std::vector<const char *> opts;
+    for (const std::string &w : words) opts.push_back(w.c_str());
     hiprtcResult rc = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     size_t ln = 0;
     hiprtcGetProgramLogSize(prog, &ln);
@@ -118,21 +130,38 @@ void mkdirs(const std::string &d)
         if (i == d.size() || d[i] == '/') (void)mkdir(d.substr(0, i).c_str(), 0777);
 }
 
-const uint32_t CACHE_MAGIC = 0x3263726du;    // "mrc2": 9 header words (guard geometry in the header)
+const uint32_t CACHE_MAGIC = 0x3363726du;    // "mrc3": 9 header words (guard geometry in the header), checksum over header and code
+
+uint64_t cache_sum(const uint32_t hdr[9], const JitCode &c)
+{
+    return fnv1a(c.rows.data(), c.rows.size(), fnv1a(c.pix.data(), c.pix.size(), fnv1a(hdr, 36, 0xcbf29ce484222325ull)));
+}
+
+// The launch geometry comes from this header (the sources it was generated for are not at hand when a file is read), so a
+// damaged one must read as a miss, not as a division by zero or a table indexed past its end: every field is range-checked
+// and the checksum covers the header too.  guard_w: 64 / 128 / 256 pixels; guard_h: a power of two up to 128 rows (1 = guards
+// per row); waves: the occupancies __launch_bounds__ is given.
+bool cache_header_ok(const uint32_t hdr[9])
+{
+    const uint32_t gw = hdr[7], gh = hdr[8];
+    return hdr[0] == CACHE_MAGIC && hdr[1] >= 1 && hdr[1] <= 65535 && hdr[2] <= 65535 && (hdr[3] == 0 || hdr[3] == 2 || hdr[3] == 4 || hdr[3] == 6 || hdr[3] == 8) &&
+           hdr[4] > 0 && hdr[4] < (1u << 30) && hdr[5] < (1u << 30) && hdr[6] <= 1024 && (gw == 64 || gw == 128 || gw == 256) &&
+           gh >= 1 && gh <= 128 && (gh & (gh - 1)) == 0;
+}
 
 bool cache_read(const std::string &path, JitCode &c)
 {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
     uint32_t hdr[9];
-    bool ok = fread(hdr, 4, 9, f) == 9 && hdr[0] == CACHE_MAGIC && hdr[4] < (1u << 30) && hdr[5] < (1u << 30);
+    bool ok = fread(hdr, 4, 9, f) == 9 && cache_header_ok(hdr);
     if (ok) {
         c.n_row_chunks = hdr[1]; c.n_gjobs = hdr[2]; c.waves = (int)hdr[3];
         c.n_gwords = hdr[6]; c.guard_w = hdr[7]; c.guard_h = hdr[8];
         c.pix.resize(hdr[4]); c.rows.resize(hdr[5]);
         ok = fread(c.pix.data(), 1, c.pix.size(), f) == c.pix.size() && fread(c.rows.data(), 1, c.rows.size(), f) == c.rows.size();
         uint64_t sum = 0;
-        ok = ok && fread(&sum, 8, 1, f) == 1 && sum == fnv1a(c.rows.data(), c.rows.size(), fnv1a(c.pix.data(), c.pix.size(), 0xcbf29ce484222325ull));
+        ok = ok && fread(&sum, 8, 1, f) == 1 && sum == cache_sum(hdr, c);
     }
     fclose(f);
     return ok;
@@ -146,7 +175,7 @@ void cache_write(const std::string &dir, const std::string &path, const JitCode 
     if (!f) return;                                       // a read-only or missing cache directory is not an error
     const uint32_t hdr[9] = {CACHE_MAGIC, c.n_row_chunks, c.n_gjobs, (uint32_t)c.waves, (uint32_t)c.pix.size(), (uint32_t)c.rows.size(),
                              c.n_gwords, c.guard_w, c.guard_h};
-    const uint64_t sum = fnv1a(c.rows.data(), c.rows.size(), fnv1a(c.pix.data(), c.pix.size(), 0xcbf29ce484222325ull));
+    const uint64_t sum = cache_sum(hdr, c);
     const bool ok = fwrite(hdr, 4, 9, f) == 9 && fwrite(c.pix.data(), 1, c.pix.size(), f) == c.pix.size() &&
                     fwrite(c.rows.data(), 1, c.rows.size(), f) == c.rows.size() && fwrite(&sum, 8, 1, f) == 1;
     if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());      // rename: readers never see half a file
@@ -311,9 +340,9 @@ HelperJob helper_start(const std::string &helper, const std::string &rtc, const 
     const bool ok = write(fd, src.data(), src.size()) == (ssize_t)src.size();
     close(fd);
     if (!ok) return j;
-    const char *olevel = getenv("MARAY_JIT_OPT");
+    const std::vector<std::string> words = jit_option_words();          // the helper compiles with the words the key was made from
     std::vector<char *> argv = {(char *)helper.c_str(), (char *)rtc.c_str(), (char *)j.src_path.c_str(), (char *)j.out_path.c_str()};
-    if (olevel && olevel[0] == '-') argv.push_back((char *)olevel);
+    for (const std::string &w : words) argv.push_back((char *)w.c_str());
     argv.push_back(nullptr);
     pid_t pid = -1;
     if (posix_spawn(&pid, helper.c_str(), nullptr, nullptr, argv.data(), environ) == 0) j.pid = pid;

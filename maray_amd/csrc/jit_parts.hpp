@@ -5,6 +5,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "backend.hpp"
 
@@ -21,6 +22,7 @@ static const unsigned ROW_BLOCK = 256;          // threads per block of the ROW 
 
 struct GuardGeom { uint32_t gw, gh; };          // the rectangle a guard is bounded over: gw pixels x gh rows (jit_guard_geom)
 
+std::vector<std::string> jit_option_words();                          // JIT_OPTIONS with MARAY_JIT_OPT / MARAY_JIT_EXTRA applied: what every compile is given (jit_build.cpp)
 bool may_defer_tiles(const maray_program &P);                       // some Sin whose argument is not provably bounded: tiles may go to the interpreter
 uint32_t jit_guard_words(const maray_program &P);                   // 64-bit words of guard bits per rectangle
 GuardGeom jit_guard_geom(const maray_program &P);

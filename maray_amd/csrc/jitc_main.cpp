@@ -1,4 +1,4 @@
-// maray_jitc HIPRTC_LIB SOURCE OUT [-Ox] — compiles one generated kernel source to a gfx950 code object with the hiprtc
+// maray_jitc HIPRTC_LIB SOURCE OUT OPTION... — compiles one generated kernel source to a gfx950 code object with the hiprtc
 // library the caller names (the one the calling process has loaded: its version is part of the code key), in a process of
 // its own: libmaray_hip.so starts one per module so that the PIXEL and the ROW kernels of a program build side by side
 // (hiprtc serialises compiles inside a process), and an LLVM abort ends this process, not the caller's.
@@ -10,7 +10,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <sstream>
 #include <string>
 #include <vector>
 
@@ -39,7 +38,7 @@ bool write_file(const char *path, const char *data, size_t n)
 
 int main(int argc, char **argv)
 {
-    if (argc < 4) { fprintf(stderr, "usage: maray_jitc HIPRTC_LIB SOURCE OUT [-Ox]\n"); return 2; }
+    if (argc < 5) { fprintf(stderr, "usage: maray_jitc HIPRTC_LIB SOURCE OUT OPTION...\n"); return 2; }
     void *lib = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
     if (!lib) { fprintf(stderr, "maray_jitc: %s\n", dlerror()); return 4; }
     const create_fn create = (create_fn)dlsym(lib, "hiprtcCreateProgram");
@@ -62,11 +61,8 @@ int main(int argc, char **argv)
     if (const char *e_ = getenv("MARAY_JITC_TEST_ABORT")) if (e_[0] == '1') abort();
     hiprtcProgram prog;
     if (create(&prog, src.c_str(), "maray_jit.hip", 3, headers, names) != 0) return 6;
-    const char *olevel = argc > 4 && argv[4][0] == '-' ? argv[4] : "-O3";
-    std::vector<const char *> opts = {"--offload-arch=gfx950", olevel, "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-mllvm", "-structurizecfg-skip-uniform-regions"};       // = jit_compile (jit_backend.cpp)
-    std::vector<std::string> extra;                        // MARAY_JIT_EXTRA, inherited from the caller's environment
-    if (const char *e_ = getenv("MARAY_JIT_EXTRA")) { std::istringstream in(e_); for (std::string w; in >> w;) extra.push_back(w); }
-    for (const std::string &w : extra) opts.push_back(w.c_str());
+    // the options are the caller's (jit_option_words, jit_build.cpp: the very words its code key was made from), one per argument
+    std::vector<const char *> opts(argv + 4, argv + argc);
     const int rc = compile(prog, (int)opts.size(), opts.data());
     if (rc != 0) {
         size_t ln = 0;

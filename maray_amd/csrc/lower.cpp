@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <unordered_map>
 #include <unordered_set>
 
@@ -238,6 +239,10 @@ Ival ival_mul(const Ival &a, const Ival &b)
     const bool a_inf = std::isinf(a.lo) || std::isinf(a.hi), b_inf = std::isinf(b.lo) || std::isinf(b.hi);
     if ((a_zero && b_inf) || (b_zero && a_inf)) { r.nan = true; r.lo = -INFINITY; r.hi = INFINITY; }
     r.lo = down(r.lo); r.hi = up(r.hi);
+    if (!r.nan) {      // the margin must not cross zero for factors of known sign
+        if ((a.lo >= 0 && b.lo >= 0) || (a.hi <= 0 && b.hi <= 0)) r.lo = std::max(r.lo, 0.0);
+        if ((a.lo >= 0 && b.hi <= 0) || (a.hi <= 0 && b.lo >= 0)) r.hi = std::min(r.hi, 0.0);
+    }
     return r;
 }
 
@@ -273,9 +278,22 @@ std::vector<Ival> intervals(const Dag &g)
             const double lo = a.lo + b.lo, hi = a.hi + b.hi;
             r = Ival{lo != lo ? -INFINITY : down(lo), hi != hi ? INFINITY : up(hi), a.nan || b.nan || lo != lo || hi != hi ||
                      (std::isinf(a.lo) && std::isinf(b.hi)) || (std::isinf(a.hi) && std::isinf(b.lo))};
+            // the outward step is a margin, not a need (rounding is monotone: fl(a + b) >= fl(a.lo + b.lo)); it must not
+            // carry a sum of non-negative terms below zero (0 + 0 -> -4.9e-324 would make the sqrt above it "may be NaN")
+            if (a.lo >= 0 && b.lo >= 0) r.lo = std::max(r.lo, 0.0);
+            if (a.hi <= 0 && b.hi <= 0) r.hi = std::min(r.hi, 0.0);
             break;
         }
-        case MARAY_OP_MUL: r = ival_mul(a, b); break;
+        case MARAY_OP_MUL:
+            r = ival_mul(a, b);
+            // a square: never below zero, whatever the corner products say (p2_len = sqrt(a*a + b*b), src/lib.rs:1027-1029,
+            // is how every signed-distance shape measures; the corner rule alone gives lo * hi < 0 for an operand that
+            // changes sign, and the sqrt above it would count as a possible NaN)
+            if (d.a == d.b && !a.nan && !r.nan) {
+                const double m = a.lo > 0 ? a.lo : (a.hi < 0 ? -a.hi : 0.0);
+                r.lo = std::max(r.lo, m > 0 ? down(m * m) : 0.0);
+            }
+            break;
         case MARAY_OP_MAX: r = Ival{std::max(a.lo, b.lo), std::max(a.hi, b.hi), a.nan && b.nan}; if (a.nan || b.nan) { r.lo = std::min(a.lo, b.lo); } break;
         case MARAY_OP_MIN: r = Ival{std::min(a.lo, b.lo), std::min(a.hi, b.hi), a.nan && b.nan}; if (a.nan || b.nan) { r.hi = std::max(a.hi, b.hi); } break;
         case MARAY_OP_APP: r = Ival{0.0, 255.0, false}; break;
@@ -325,6 +343,19 @@ std::vector<Mono> monotonicity(const Dag &g, const std::vector<Ival> &iv, uint8_
             // one factor must be fixed along the row; its sign decides the direction
             const int32_t v = (b == M_CONSTX) ? d.a : (a == M_CONSTX ? d.b : -1);
             const int32_t c = (b == M_CONSTX) ? d.b : d.a;
+            if (v < 0 && (a == M_INC || a == M_DEC) && (b == M_INC || b == M_DEC)) {
+                // both factors vary: monotone when both are sign-definite and their MAGNITUDES move the same way
+                // (0 <= f1 <= f2, 0 <= g1 <= g2  =>  f1 g1 <= f2 g2 in the reals, and rounding is monotone); the sign of
+                // the product then says which way the value goes.  Covers squares of sign-definite terms.
+                const Ival &fa = iv[d.a], &fb = iv[d.b];
+                const int sa = fa.lo >= 0 ? 1 : (fa.hi <= 0 ? -1 : 0), sb = fb.lo >= 0 ? 1 : (fb.hi <= 0 ? -1 : 0);
+                if (sa && sb) {
+                    const Mono ma = sa > 0 ? a : flip(a), mb = sb > 0 ? b : flip(b);      // direction of |f|, |g|
+                    if (ma == mb) { m[i] = sa * sb > 0 ? ma : flip(ma); break; }
+                }
+                m[i] = M_NONE;
+                break;
+            }
             if (v < 0 || m[v] == M_NONE) { m[i] = M_NONE; break; }
             if (iv[c].lo >= 0) m[i] = m[v];
             else if (iv[c].hi <= 0) m[i] = flip(m[v]);
@@ -412,7 +443,9 @@ struct RowBounds {
                 if (!a.ok()) break;
                 if (rng(d.a).lo >= 0) r = a;
                 else if (rng(d.a).hi <= 0) r = {g.unary(MARAY_OP_NEG, a.hi), g.unary(MARAY_OP_NEG, a.lo)};
-                else r = {c_false /* +0.0 */, g.binary(MARAY_OP_MAX, g.unary(MARAY_OP_ABS, a.lo), g.unary(MARAY_OP_ABS, a.hi))};
+                else      // may change sign over the domain: over THIS span it is at least its distance from zero, max(lo, -hi, +0)
+                    r = {g.binary(MARAY_OP_MAX, g.binary(MARAY_OP_MAX, a.lo, g.unary(MARAY_OP_NEG, a.hi)), c_false),
+                         g.binary(MARAY_OP_MAX, g.unary(MARAY_OP_ABS, a.lo), g.unary(MARAY_OP_ABS, a.hi))};
                 break;
             }
             case MARAY_OP_ADD: case MARAY_OP_MIN: case MARAY_OP_MAX: {
@@ -425,7 +458,15 @@ struct RowBounds {
                 if (!a.ok() || !b.ok()) break;
                 const Ival ra = rng(d.a), rb = rng(d.b);
                 auto mul = [&](int32_t p, int32_t q) { return g.binary(MARAY_OP_MUL, p, q); };
-                if (ra.lo >= 0 && rb.lo >= 0) r = {mul(a.lo, b.lo), mul(a.hi, b.hi)};
+                if (d.a == d.b && !(ra.lo >= 0) && !(ra.hi <= 0)) {
+                    // a square of something that may change sign over the domain: [m * m, max(lo * lo, hi * hi)] with
+                    // m = max(lo, -hi, +0) the operand's distance from zero over the span (fl(v * v) >= fl(m * m) for
+                    // |v| >= m; 0 when the span straddles zero) -- the corner rule below would answer lo * hi < 0
+                    const int32_t m = g.binary(MARAY_OP_MAX, g.binary(MARAY_OP_MAX, a.lo, g.unary(MARAY_OP_NEG, a.hi)), c_false);
+                    r = {mul(m, m), g.binary(MARAY_OP_MAX, mul(a.lo, a.lo), mul(a.hi, a.hi))};
+                    fired_sq++;
+                }
+                else if (ra.lo >= 0 && rb.lo >= 0) r = {mul(a.lo, b.lo), mul(a.hi, b.hi)};
                 else if (ra.hi <= 0 && rb.hi <= 0) r = {mul(a.hi, b.hi), mul(a.lo, b.lo)};
                 else if (ra.lo >= 0 && rb.hi <= 0) r = {mul(a.hi, b.lo), mul(a.lo, b.hi)};
                 else if (ra.hi <= 0 && rb.lo >= 0) r = {mul(a.lo, b.hi), mul(a.hi, b.lo)};
@@ -438,9 +479,21 @@ struct RowBounds {
             }
             default: break;
             }
+            if (r.ok() && d.op < MARAY_OP_COUNT) fired[d.op]++;
         }
+        else if (r.ok()) fired_mono++;
         iv_memo.emplace(i, r);
         return r;
+    }
+    // which rules produced an interval (MARAY_TRACE_LOWER=1 prints them: what a fuzz family reaches)
+    uint32_t fired[MARAY_OP_COUNT] = {}, fired_mono = 0, fired_sq = 0;
+    void trace(const char *pass) const {
+        static const char *names[] = {"MOV", "NEG", "ABS", "RECIP", "SQRT", "STEP", "ADD", "MUL", "MAX", "MIN"};
+        static const uint8_t ops[] = {MARAY_OP_MOV, MARAY_OP_NEG, MARAY_OP_ABS, MARAY_OP_RECIP, MARAY_OP_SQRT, MARAY_OP_STEP, MARAY_OP_ADD,
+                                      MARAY_OP_MUL, MARAY_OP_MAX, MARAY_OP_MIN};
+        fprintf(stderr, "maray lower: interval rules fired, bounds over %s: end points of monotone values %u, squares %u", pass, fired_mono, fired_sq);
+        for (size_t k = 0; k < sizeof ops; k++) fprintf(stderr, ", %s %u", names[k], fired[ops[k]]);
+        fprintf(stderr, "\n");
     }
 
     // For an arithmetic value v: an expression free of the coordinate with  zub == 0  =>  v is +0.0 (that very bit
@@ -1123,16 +1176,48 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         // [YMIN, YMAX] the same way, and then holds for a rectangle of pixels -- an evaluator may compute it once for
         // several rows.  A guard that is not keeps reading Y: exact for its row, valid for that row only.
         lap("  bounds over x");
+        if (trace) rb.trace("x");
         if (opts.no_y_spans == 0) {
             const std::vector<uint8_t> isb1 = bool_typing();
             const std::vector<Ival> iv1 = intervals(g);
             const std::vector<Mono> mono_y = monotonicity(g, iv1, DEP_Y, D_Y);
             RowBounds rby(g, isb1, mono_y, iv1, DEP_Y, D_Y, D_YMIN, D_YMAX);
+            // A lift that had to give up on some sub-expression (`lossy`: a y-only Step(Sin) of a pattern, say, bounded by
+            // "anything") is weaker than the guard it comes from, which is exact for its row; one that gave up on all of it is
+            // the constant 1.  The evaluators bound guards per rectangle of pixels only when NO guard of the program reads Y
+            // (any_guard_reads_y), per row x span otherwise -- 32 times the guard work and none of the specialised kernel's
+            // rectangle machinery.  So when most guards that read Y have a lift worth having, every one of them takes its
+            // lift, exact or not, and the few that have none are dropped (a guard is an optimisation: without it the region
+            // is simply evaluated); otherwise only exact lifts are taken, as the guards stay per row anyway.
+            std::vector<std::pair<size_t, RowBounds::B>> lifts;
+            size_t n_real = 0, n_none = 0;
             for (size_t i = 0; i < N0; i++) {
-                if (rowub[i] < 0) continue;
+                if (rowub[i] < 0 || !(g.n[rowub[i]].dep & DEP_Y)) continue;
                 const RowBounds::B u = rby.bounds(rowub[i]);
-                if (!u.lossy && g.n[u.ub].op < D_CONST) rowub[i] = u.ub;
+                lifts.push_back({i, u});
+                (g.n[u.ub].op < D_CONST ? n_real : n_none)++;
             }
+            const bool all_free = n_real > 0 && n_real >= n_none;
+            if (trace && getenv("MARAY_TRACE_GUARDS")) {
+                std::function<std::string(int32_t, int)> show = [&](int32_t i, int depth) -> std::string {
+                    const DNode &d = g.n[i];
+                    static const char *leaf[] = {"", "X", "Y", "XMAX", "XMIN", "YMAX", "YMIN"};
+                    static const char *opn[] = {"nop", "mov", "neg", "abs", "recip", "sqrt", "step", "sin", "exp", "ln", "add", "mul", "max", "min", "app", "texdim", "out", "stepsin"};
+                    if (d.op == D_CONST) { char b[32]; snprintf(b, sizeof b, "%g", d.cval); return b; }
+                    if (d.op > D_CONST) return leaf[d.op - D_CONST];
+                    if (depth <= 0) return "...";
+                    std::string r = std::string("(") + opn[d.op] + " " + show(d.a, depth - 1);
+                    if (d.b >= 0) r += " " + show(d.b, depth - 1);
+                    return r + ")";
+                };
+                for (auto &l : lifts) fprintf(stderr, "maray lower: node %zu guard %s\n   lift %s lossy %d\n", l.first, show(rowub[l.first], 12).c_str(), show(l.second.ub, 12).c_str(), (int)l.second.lossy);
+            }
+            if (trace) fprintf(stderr, "maray lower: guards over y: %zu lifted, %zu without a lift -> %s\n", n_real, n_none, all_free ? "rectangles" : "rows");
+            for (auto &l : lifts) {
+                if (g.n[l.second.ub].op < D_CONST) { if (!l.second.lossy || all_free) rowub[l.first] = l.second.ub; }
+                else if (all_free) rowub[l.first] = -1;
+            }
+            if (trace) rby.trace("y");
         }
         rowub.resize(g.n.size(), -1);
     }

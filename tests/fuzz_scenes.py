@@ -113,3 +113,75 @@ def subst_xy(e, ex, ey):
     if e[0] == 'X': return ex
     if e[0] == 'Y': return ey
     return tuple(subst_xy(c, ex, ey) if isinstance(c, tuple) and c and isinstance(c[0], str) else c for c in e)
+
+
+def curved_soup(seed, n, w, h, mixed=False):
+    """n random CURVED shapes painted over one another: the gating shapes are not half-planes but signed-distance
+    circles, boxes and rounded boxes (Sd2, /root/reference/src/sd.rs:28-48: sqrt, abs, max / min of differences), cubic
+    Bezier strokes (p2_cbez, src/lib.rs:1061-1065, the curve's y at a clamped parameter of x, a band of |y - c(t)|
+    around it) and 1/(1 + d^2) falloffs cut at a level -- so that the sqrt / recip / abs / corner-product paths of the
+    lowering's interval bounds (RowBounds::ival, lower.cpp) decide which rectangles of pixels skip a shape.  Each
+    shape carries a pattern in its own frame (a cone worth guarding); `mixed`: False = one mask for the three channels,
+    True = channels paint different subsets, 'colours' = channel = max_i(shape_i * falloff_i): max trees of non-booleans."""
+    from marayb import (abs_, chess, clamp_unit, p2_cbez, p2_lerp, p2_pos, p4_xy, p4_zw, pos, range_, sd_box, sd_circle, sd_inside,
+                        set_inv, subst2, translate)
+    rng = random.Random(0xC0FFEE + seed)
+    shapes, falloffs = [], []
+    for _ in range(n):
+        cx, cy = rng.randrange(0, w), rng.randrange(0, h)
+        r = rng.choice([5, 9, 17, 33, 70])
+        off = [nat(cx), nat(cy)]
+        kind = rng.choice(['circle', 'box', 'rbox', 'stroke', 'falloff', 'ring'])
+        dx, dy = sub(x(), nat(cx)), sub(y(), nat(cy))
+        d2 = add(mul(dx, dx), mul(dy, dy))
+        if kind == 'circle':
+            inside = sd_inside(translate(sd_circle(nat(r)), off))
+        elif kind == 'box':
+            inside = sd_inside(translate(sd_box([nat(r), nat(max(2, r // rng.choice([1, 2, 3])))]), off))
+        elif kind == 'rbox':                              # Sd2::RoundedBox, src/sd.rs:39-47
+            b = [nat(r), nat(max(3, r // 2))]
+            rr = [div(nat(rng.randrange(1, 5)), nat(2)) for _ in range(4)]
+            rxy = p2_pos(x(), p4_xy(rr), p4_zw(rr))
+            rx = pos(y(), rxy[0], rxy[1])
+            q = [add(sub(abs_(x()), b[0]), rx), add(sub(abs_(y()), b[1]), rx)]
+            sd = sub(add(min_(max_(q[0], q[1]), nat(0)), sqrt(add(mul(max_(q[0], nat(0)), max_(q[0], nat(0))), mul(max_(q[1], nat(0)), max_(q[1], nat(0)))))), rx)
+            inside = sd_inside(translate(sd, off))
+        elif kind == 'stroke':                            # the band |y - c_y(t(x))| <= th over x in [x0, x0 + L)
+            L = rng.choice([40, 90, 200])
+            x0 = max(0, cx - L // 2)
+            t = clamp_unit(mul(sub(x(), nat(x0)), div(nat(1), nat(L))))
+            pts = [[nat(x0 + L * k // 3), nat(max(0, cy + rng.randrange(-r, r + 1)))] for k in range(4)]
+            c = p2_cbez(pts[0], pts[1], pts[2], pts[3], t)
+            th = nat(rng.choice([2, 4, 7]))
+            inside = min_(step(sub(th, abs_(sub(y(), c[1])))), range_(nat(x0), nat(x0 + L), x()))
+        elif kind == 'falloff':                           # 1 / (1 + d^2 / s) >= 1/k  <=>  d^2 <= (k - 1) s
+            s_, k = rng.choice([4, 16, 50]), rng.choice([2, 5, 17])
+            inside = step(sub(recip(add(nat(1), mul(d2, div(nat(1), nat(s_))))), div(nat(1), nat(k))))
+        else:                                             # ring: r/2 <= d <= r, through two sqrt tests
+            d = sqrt(d2)
+            inside = min_(step(sub(nat(r), d)), step(sub(d, div(nat(r), nat(2)))))
+        u, v = mul(dx, div(nat(1), nat(max(2, r // 2)))), mul(dy, div(nat(1), nat(max(2, r // 2))))
+        pat = rng.random()
+        if pat < 0.45:
+            pattern = subst_xy(chess(rng.choice([2, 4])), u, v)
+        elif pat < 0.75:
+            pattern = step(sin(add(mul(u, nat(3)), mul(v, v))))
+        else:
+            pattern = None
+        shapes.append(inside if pattern is None else min_(inside, pattern))
+        falloffs.append(recip(add(nat(1), mul(d2, div(nat(1), nat(4 * r * r))))))
+
+    def paint(items):
+        acc = items[0]
+        for t in items[1:]:
+            acc = max_(acc, t)
+        return acc
+    grad = mul(add(x(), mul(y(), nat(3))), div(nat(1), nat(w + 3 * h)))
+    if mixed == 'colours':
+        return [mul(max_(paint([mul(s_, mul(f, div(nat(k + 2), nat(4)))) for s_, f in zip(shapes, falloffs)]), mul(grad, div(nat(1), nat(8)))), nat(200))
+                for k in range(3)]
+    if not mixed:
+        m = paint(shapes)
+        return [mul(m, nat(255)), mul(max_(m, mul(grad, div(nat(1), nat(2)))), nat(255)), mul(add(mul(m, div(nat(3), nat(4))), mul(grad, div(nat(1), nat(4)))), nat(255))]
+    return [mul(paint(shapes), nat(255)), mul(max_(paint(shapes[::2]), mul(grad, div(nat(1), nat(2)))), nat(255)),
+            mul(add(mul(paint(shapes[1::2] or shapes), div(nat(3), nat(4))), mul(grad, div(nat(1), nat(4)))), nat(255))]

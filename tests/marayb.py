@@ -100,6 +100,7 @@ def p2_scale(a, b): return p2_mul(a, [b, b])
 def p2_dot(a, b): return add(mul(a[0], b[0]), mul(a[1], b[1]))
 def p2_len(a): return sqrt(p2_dot(a, a))
 def p2_lerp(a, b, t): return [lerp(a[0], b[0], t), lerp(a[1], b[1], t)]
+def p2_pos(cond, a, b): return p2_lerp(b, a, step_pos(cond))                             # src/lib.rs:983-985
 
 
 def quad_to_tri(quad, uv):   # src/lib.rs:1078-1085

@@ -94,19 +94,37 @@ def test_polygon_soups_lowering_vs_oracle():
         assert same_f64(tape_eval.render_rows_waves(tape, w, 0, h, tile=64, yrows=8), want64), seed
 
 
-@pytest.mark.gpu
-def test_polygon_soups_gpu_vs_oracle():
-    """Six soups of 70 polygons (one tree, shapes shared by two channels' trees, a colour per shape): the three evaluators
-    agree on every pixel (u8 and f64 planes), and the oracle -- six seconds a soup for the whole raster, which was most of
-    this test -- is asked for three bands of rows (top, middle, bottom)."""
-    from fuzz_scenes import polygon_soup
-    w, h = 1024, 200
-    cases = []
-    for seed in range(10, 16):
-        data = encode((w, h), polygon_soup(seed, 70, w, h, mixed=(True, False, 'colours')[seed % 3]))
-        cases.append((seed, data, M.Scene(data).lower()))
-    jit = _jit_contexts([(tape, None) for _, _, tape in cases])
-    for (seed, data, tape), jctx in zip(cases, jit):
+def test_curved_soups_lowering_vs_oracle():
+    """The third soup family: the gating shapes are circles, boxes and rounded boxes (Sd2), cubic Bezier strokes and
+    1/(1 + d^2) falloffs (fuzz_scenes.curved_soup) -- the sqrt / abs / recip / square / corner-product rules of the
+    lowering's interval bounds (RowBounds::ival) decide which spans and rectangles skip a shape.  Every pixel against
+    the oracle with SKIP ops ignored, taken per wavefront, per 64-pixel span, and per rectangle of 64 x 8 and 64 x 32 pixels
+    (what the specialised kernels take).  profiles/r4_curved_fuzz.txt logs a sweep of 220 more."""
+    from fuzz_scenes import curved_soup
+    w, h = 256, 64
+    for seed, kind in ((300, False), (301, True), (302, 'colours'), (303, False)):
+        data = encode((w, h), curved_soup(seed, 24, w, h, mixed=kind))
+        tape = M.Scene(data).lower()
+        n_guards, n_read_y = tape_eval.guards_reading_y(tape)
+        assert n_guards >= 8 and n_read_y == 0, (seed, n_guards, n_read_y)       # every guard holds for a rectangle
+        _, want64 = OScene(data).render_rows(w, h, 0, h)
+        assert same_f64(tape_eval.render_rows(tape, w, 0, h), want64), seed
+        assert same_f64(tape_eval.render_rows_waves(tape, w, 0, h), want64), seed
+        assert same_f64(tape_eval.render_rows_waves(tape, w, 0, h, tile=64), want64), seed
+        assert same_f64(tape_eval.render_rows_waves(tape, w, 0, h, tile=64, yrows=8), want64), seed
+        assert same_f64(tape_eval.render_rows_waves(tape, w, 0, h, tile=64, yrows=32), want64), seed
+
+
+def _soups_on_the_gpu(cases, w, h):
+    """cases: (name, scene bytes).  The three evaluators agree on every pixel (u8 and f64 planes); the GUARD-FREE lowering
+    of the same scene (no SKIP op, no guard, no rebalanced chain, no private region: every pixel evaluates the whole DAG
+    as /root/reference/src/lib.rs:623-670 does) gives the same raster on every pixel -- the three share one lowering and
+    its guards, this one shares neither; and the oracle is asked for three bands of rows drawn per scene (seeded), six
+    seconds a soup for the whole raster being most of what this test used to cost."""
+    import random
+    tapes = [M.Scene(data).lower() for _, data in cases]
+    jit = _jit_contexts([(tape, None) for tape in tapes])
+    for (name, data), tape, jctx in zip(cases, tapes, jit):
         got = {}
         for b in (M.BACKEND_JIT, M.BACKEND_TAPE, M.BACKEND_TAPE_SMEM):
             ctx = jctx if b == M.BACKEND_JIT else M.Context(tape, backend=b)
@@ -114,13 +132,43 @@ def test_polygon_soups_gpu_vs_oracle():
             ctx.close()
         ref8, ref64 = got[M.BACKEND_TAPE_SMEM]
         for b in (M.BACKEND_JIT, M.BACKEND_TAPE):
-            assert same_f64(got[b][1], ref64), (seed, b)
-            assert np.array_equal(got[b][0], ref8), (seed, b)
+            assert same_f64(got[b][1], ref64), (name, b)
+            assert np.array_equal(got[b][0], ref8), (name, b)
+        bare = M.Scene(data).lower(skips=False)
+        assert bare.info['skip_ops'] == 0 and bare.info['private_regions'] == 0
+        ctx = M.Context(bare, backend=M.BACKEND_TAPE_SMEM)
+        free8, free64 = ctx.render_rows(w, h, 0, h)
+        ctx.close()
+        assert same_f64(free64, ref64), (name, 'guard-free')
+        assert np.array_equal(free8, ref8), (name, 'guard-free')
         o = OScene(data)
-        for y0, y1 in ((0, 8), (96, 104), (192, 200)):
-            want8, want64 = o.render_rows(w, h, y0, y1)
-            assert same_f64(ref64[y0:y1], want64), (seed, y0)
-            assert np.array_equal(ref8[y0:y1], want8), (seed, y0)
+        rng = random.Random(name)             # (seeded by the scene's name: the same bands on every run)
+        for y0 in sorted(rng.sample(range(0, h - 8), 3)):
+            want8, want64 = o.render_rows(w, h, y0, y0 + 8)
+            assert same_f64(ref64[y0:y0 + 8], want64), (name, y0)
+            assert np.array_equal(ref8[y0:y0 + 8], want8), (name, y0)
+
+
+@pytest.mark.gpu
+def test_polygon_soups_gpu_vs_oracle():
+    """Six soups of 70 polygons (one tree, shapes shared by two channels' trees, a colour per shape): see _soups_on_the_gpu.
+    test_polygon_soups_lowering_vs_oracle holds the same family against the oracle on every pixel on the CPU."""
+    from fuzz_scenes import polygon_soup
+    w, h = 1024, 200
+    _soups_on_the_gpu([('polygons %d' % seed, encode((w, h), polygon_soup(seed, 70, w, h, mixed=(True, False, 'colours')[seed % 3])))
+                       for seed in range(10, 16)], w, h)
+
+
+@pytest.mark.gpu
+def test_curved_soups_gpu_vs_oracle():
+    """Six soups of 60 curved shapes (circles, boxes, rounded boxes, Bezier strokes, falloffs, rings): the guards of these
+    come from the sqrt / abs / recip / square interval rules; see _soups_on_the_gpu."""
+    from fuzz_scenes import curved_soup
+    w, h = 1024, 200
+    cases = [('curved %d' % seed, encode((w, h), curved_soup(seed, 60, w, h, mixed=(True, False, 'colours')[seed % 3]))) for seed in range(400, 406)]
+    for _, data in cases:
+        assert tape_eval.guards_reading_y(M.Scene(data).lower())[1] == 0
+    _soups_on_the_gpu(cases, w, h)
 
 
 @pytest.mark.gpu

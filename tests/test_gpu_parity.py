@@ -125,6 +125,17 @@ def test_chess_4096_rescaled(chess_bytes):
         assert hashlib.sha256(sub8.tobytes()).hexdigest() == g['rgb8_sha256'], b
     assert np.array_equal(full[M.BACKEND_JIT], full[M.BACKEND_TAPE_SMEM])
     assert np.array_equal(full[M.BACKEND_JIT], full[M.BACKEND_TAPE])
+    # ... and all three share one lowering and the same rectangle guards: an unsound bound (RowBounds' interval arithmetic)
+    # would blank the same rectangle in all of them.  So the WHOLE frame once more from the guard-free lowering -- no SKIP
+    # op, no guard, no rebalanced chain, no private region: every pixel evaluates the scene's whole DAG as
+    # /root/reference/src/lib.rs:623-670 does -- on the scalar-cache interpreter, every byte against the headline kernel's.
+    bare = s.lower(skips=False)
+    assert bare.info['skip_ops'] == 0 and bare.info['n_yvals'] == 292 and bare.info['private_regions'] == 0
+    ctx = M.Context(bare, backend=M.BACKEND_TAPE_SMEM)
+    free8, _ = ctx.render_rows(4096, 4096, 0, 4096, want_f64=False)
+    ctx.close()
+    assert np.array_equal(free8, full[M.BACKEND_JIT])
+    del free8
     # the same frame in one device-resident launch per ragged row range: geometry the bench and gen_to_image use
     ctx = M.Context(tape, backend=M.BACKEND_JIT)
     for y0, y1 in ((0, 2053), (2053, 4096)):
@@ -190,6 +201,17 @@ jit.render_rows_device(w, h, 0, h, d_rgb8=a.data_ptr())            # ONE launch 
 ref.render_rows_device(w, h, 0, h, d_rgb8=b.data_ptr())
 torch.cuda.synchronize()
 assert torch.equal(a, b), 'one-launch raster differs from the interpreter'
+# the two share the lowering and its rectangle guards; the guard-free lowering (every pixel evaluates the whole DAG:
+# no SKIP op, no guard, no rebalancing, no private regions) shares neither
+bare = s.lower(skips=False)
+assert bare.info['skip_ops'] == 0 and bare.info['private_regions'] == 0
+free = M.Context(bare, backend=M.BACKEND_TAPE_SMEM)
+b.fill_(5)
+for y0 in range(0, h, 1024):                      # ~0.6 s a band at the bare lowering's 27 Mpx/s
+    free.render_rows_device(w, h, y0, y0 + 1024, d_rgb8=b.data_ptr() + y0 * w * 3)
+    torch.cuda.synchronize()
+assert torch.equal(a, b), 'one-launch raster differs from the guard-free evaluation'
+free.close()
 g = json.load(open(%(golden)r))
 assert hashlib.sha256(np.ascontiguousarray(a[::16, ::16].cpu().numpy()).tobytes()).hexdigest() == g['rgb8_sha256']
 # rank 3 of 8 of `bench.py --scaling strong`: 64-row blocks 3, 11, 19, ... in one launch

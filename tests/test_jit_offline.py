@@ -204,6 +204,50 @@ def test_a_helper_that_dies_compiling_is_an_error_not_a_retry_in_process(monkeyp
     assert blob[:4] == b'\x7fELF'
 
 
+def test_a_damaged_cache_file_is_a_miss(tmp_path):
+    """The launch geometry of cached kernels comes from the .mrco header: a damaged header -- even one whose checksum has
+    been made to fit -- must read as a miss and be rebuilt, not divide by a zero guard width or under-size a guard table
+    (ADVICE round 3).  Each step in a process of its own: the process's own table would hide the file."""
+    import glob
+    import struct
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, ctypes as C\nsys.path[:0] = [%r, %r]\nimport maray_amd as M, scenes\nfrom marayb import encode\n"
+            "t = M.Scene(encode((72, 40), scenes.all_ops(72, 40))).lower()\nL = M.lib()\n"
+            "L.maray_jit_build.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]\n"
+            "c, n = C.c_void_p(), C.c_size_t()\nrc = L.maray_jit_build(C.byref(t.program), C.byref(c), C.byref(n))\n"
+            "print(rc, n.value)\n" % (root, os.path.join(root, 'tests')))
+    env = dict(os.environ, MARAY_CACHE_DIR=str(tmp_path), AMD_COMGR_CACHE='0')
+
+    def run():
+        out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=600)
+        assert out.returncode == 0 and out.stdout.split()[0] == '0', out.stdout + out.stderr[-800:]
+        return int(out.stdout.split()[1])
+    n0 = run()
+    (path,) = glob.glob(str(tmp_path / '*.mrco'))
+    good = open(path, 'rb').read()
+    hdr = list(struct.unpack('<9I', good[:36]))
+    assert hdr[0] == 0x3363726d and hdr[4] == n0 and hdr[7] in (64, 128, 256) and len(good) == 36 + hdr[4] + hdr[5] + 8
+
+    def fnv(data, h=0xcbf29ce484222325):
+        for b in data:
+            h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+        return h
+    assert struct.unpack('<Q', good[-8:])[0] == fnv(good[36 + hdr[4]:-8], fnv(good[36:36 + hdr[4]], fnv(good[:36])))     # the sum covers the header
+    for field, value in ((7, 0), (7, 96), (8, 24), (8, 0), (6, 5000), (3, 3), (1, 0)):
+        bad = list(hdr)
+        bad[field] = value
+        head = struct.pack('<9I', *bad)
+        body = good[36:-8]
+        forged = head + body + struct.pack('<Q', fnv(good[36 + hdr[4]:-8], fnv(good[36:36 + hdr[4]], fnv(head))))   # checksum made to fit
+        for blob in (forged, head + body + good[-8:]):
+            open(path, 'wb').write(blob)
+            os.utime(path, (1, 1))
+            assert run() == n0                                   # rebuilt, same kernels
+            assert open(path, 'rb').read() == good               # ... and the file is whole again
+
+
 def _sources(tape):
     L = M.lib()
     L.maray_jit_source.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]

@@ -81,3 +81,56 @@ def test_two_ranks_render_disjoint_row_tiles(tmp_path):
     mp.spawn(_worker, args=(2, port, data, w, h, out), nprocs=2, join=True)
     want8, _ = OScene(data).render_rows(w, h, 0, h)
     assert np.array_equal(np.load(out), want8)
+
+
+def test_launcher_env_arithmetic():
+    """What `bench.py --gpus N` gives each of the ranks it starts (the driver's plain command line, no torchrun)."""
+    from maray_amd.sharding import device_of_rank, rank_envs
+    envs = rank_envs(4, 29511, base={'PATH': '/bin', 'WORLD_SIZE': 'stale'})
+    assert [e['RANK'] for e in envs] == ['0', '1', '2', '3'] == [e['LOCAL_RANK'] for e in envs]
+    assert all(e['WORLD_SIZE'] == '4' and e['LOCAL_WORLD_SIZE'] == '4' for e in envs)
+    assert all(e['MASTER_ADDR'] == '127.0.0.1' and e['MASTER_PORT'] == '29511' and e['PATH'] == '/bin' for e in envs)
+    assert all(e['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' for e in envs)
+    assert rank_envs(1, 1, base={'HSA_ENABLE_IPC_MODE_LEGACY': '1'})[0]['HSA_ENABLE_IPC_MODE_LEGACY'] == '1'   # the caller's choice stays
+    # one rank per device; fewer devices than ranks: shared round-robin, and said to be a rehearsal
+    assert [device_of_rank(r, 8, 8) for r in range(8)] == [(r, False) for r in range(8)]
+    assert [device_of_rank(r, 2, 1) for r in range(2)] == [(0, True), (0, True)]
+    assert [device_of_rank(r, 4, 2) for r in range(4)] == [(0, True), (1, True), (0, True), (1, True)]
+    assert device_of_rank(0, 1, 8) == (0, False)
+    with pytest.raises(ValueError):
+        device_of_rank(0, 2, 0)
+
+
+def test_launcher_relays_rank_zero_and_fails_with_any_rank():
+    from maray_amd.sharding import launch_ranks
+    prog = ("import os, sys, time\n"
+            "r = int(os.environ['RANK'])\n"
+            "print('rank %d of %s local %s' % (r, os.environ['WORLD_SIZE'], os.environ['LOCAL_RANK']), flush=True)\n"
+            "sys.exit(int(sys.argv[1]) if r == int(sys.argv[2]) else 0) if len(sys.argv) > 2 and sys.argv[3] == 'now' else None\n"
+            "time.sleep(60 if len(sys.argv) > 2 and r != int(sys.argv[2]) else 0)\n")
+    rc, out = launch_ranks([sys.executable, '-c', prog], 3)
+    assert rc == 0 and out.strip() == 'rank 0 of 3 local 0'              # only rank 0's stdout comes back
+    import time
+    t = time.monotonic()
+    rc, out = launch_ranks([sys.executable, '-c', prog, '7', '2', 'now'], 3)   # rank 2 fails, the others would sleep a minute
+    assert rc == 7 and time.monotonic() - t < 30
+    rc, _ = launch_ranks([sys.executable, '-c', 'import time; time.sleep(60)'], 2, timeout=0.5)
+    assert rc == 124
+
+
+def test_bench_starts_its_own_ranks_and_fails_loudly_without_a_device():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts two ranks; here they find no HIP device,
+    so there is no JSON line and the exit code is not 0 (never a CPU fallback, never an `n_gpus: 1` line)."""
+    import subprocess
+    if torch.cuda.device_count() > 0:
+        pytest.skip('a GPU is visible: covered by the GPU suite')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and '{' not in r.stdout
+    assert r.stderr.count('no HIP device is visible') == 2 and '2-rank run failed' in r.stderr
+    # a rank count that does not match --gpus is refused rather than printed as something else
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, env=dict(env, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0'), timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE=2' in r.stderr
