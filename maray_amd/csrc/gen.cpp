@@ -138,18 +138,19 @@ std::shared_ptr<GenEntry> gen_cache_insert(std::shared_ptr<GenEntry> fresh)
 // choice made for the FIRST call's size: an interpreter context taken for a thumbnail is not what a 16384^2 frame
 // wants, so a kept interpreter context is dropped (the caller makes a new one, AUTO decides again) when this call is
 // to render more than it was chosen for.
-maray_ctx *gen_cache_take(GenEntry &e, int dev, bool auto_backend, uint32_t hint_mpixels)
+IdleCtx gen_cache_take(GenEntry &e, int dev, bool auto_backend, uint32_t hint_mpixels)
 {
-    maray_ctx *stale = nullptr, *c = nullptr;
+    maray_ctx *stale = nullptr;
+    IdleCtx c;
     {
         std::lock_guard<std::mutex> lk(g_gen_mutex);
         auto it = e.idle.find(dev);
-        if (it == e.idle.end()) return nullptr;
+        if (it == e.idle.end()) return c;
         const IdleCtx ic = it->second;
         e.idle.erase(it);
         const bool interp = strncmp(maray_hip_kernel_name(ic.ctx), "maray_jit", 9) != 0;
         if (auto_backend && interp && ic.hint_mpixels != 0 && (hint_mpixels == 0 || hint_mpixels > ic.hint_mpixels)) stale = ic.ctx;
-        else c = ic.ctx;
+        else c = ic;
     }
     if (stale) maray_hip_ctx_free(stale);
     return c;
@@ -291,14 +292,14 @@ extern "C" int maray_gen_to_image(const maray_scene *s, const maray_texture *tex
     auto worker = [&](uint32_t d) {
         // worker d's context: the one an earlier call left (same program, same worker slot), or a new one
         const int dev = wrap ? (int)(d % (uint32_t)n_dev_avail) : (int)d;
-        maray_ctx *ctx = gen_cache_take(*entry, dev, co.backend == MARAY_BACKEND_AUTO, co.hint_mpixels);
-        const bool kept = ctx != nullptr;
+        const IdleCtx kept = gen_cache_take(*entry, dev, co.backend == MARAY_BACKEND_AUTO, co.hint_mpixels);
+        maray_ctx *ctx = kept.ctx;
         int r = ctx ? MARAY_OK : maray_hip_ctx_create(dev, &prog, tex, n_tex, &co, &ctx);
         if (!r && !share[d].empty())
             r = maray_hip_render_tiles(ctx, w, h, share[d].data(), (uint32_t)(share[d].size() / 2), rgb8, on_tile, &tu);
         const std::string msg = r ? maray_last_error() : "";      // this thread's message, re-raised on the calling thread
         if (r) maray_hip_ctx_free(ctx);                           // (a context that failed is not kept)
-        else gen_cache_give(*entry, dev, ctx, kept ? 0u : co.hint_mpixels);
+        else gen_cache_give(*entry, dev, ctx, kept.ctx ? kept.hint_mpixels : co.hint_mpixels);      // (what it was CHOSEN for)
         std::lock_guard<std::mutex> lk(P.m);
         if (r && !P.failed) { P.failed = r; P.err = msg; }
         P.finished++;

@@ -444,6 +444,72 @@ def test_gen_to_image_with_four_workers_on_the_devices_present(chess_bytes, monk
         M.gen_to_image(s, n_devices=M.device_count() + 1)
 
 
+def test_gen_to_image_keeps_contexts_per_device_and_rechooses_under_auto(chess_bytes, monkeypatch, tmp_path):
+    """What maray_gen_to_image keeps between calls (gen.cpp).  (1) Contexts are kept per PHYSICAL device: after a call whose
+    four workers shared the devices present (MARAY_GEN_WRAP_DEVICES) the idle contexts are listed under the devices they
+    live on, none under a worker number past the devices.  (2) Under MARAY_BACKEND_AUTO a kept context stands for the
+    choice made for the first call's size: a thumbnail takes the interpreter (nothing to build), and a later, larger call
+    -- once the specialised kernels are in the code cache -- must not inherit that interpreter context."""
+    monkeypatch.setenv('MARAY_CACHE_DIR', str(tmp_path / 'cache'))
+    M.gen_cache_clear()
+    n_dev = M.device_count()
+    s = M.Scene(chess_bytes)
+    s.rescale(2, 1)                                                  # 2048 x 1024: a program of this test's own
+    monkeypatch.setenv('MARAY_GEN_WRAP_DEVICES', '1')
+    a = M.gen_to_image(s, backend=M.BACKEND_TAPE_SMEM, n_devices=4, tile_rows=64)
+    monkeypatch.delenv('MARAY_GEN_WRAP_DEVICES')
+    info = M.gen_cache_info()
+    assert len(info) == 4 and all(int(line.split(' device ')[1].split()[0]) < n_dev for line in info), info
+    b = M.gen_to_image(s, backend=M.BACKEND_TAPE_SMEM, n_devices=1)  # takes a context of device 0, whichever worker left it
+    assert np.array_equal(a, b)
+    M.gen_cache_clear()
+    # AUTO: 64 x 64 first (hint: 1 Mpixel, nothing cached -> the interpreter) ...
+    small = M.gen_to_image(s, backend=M.BACKEND_AUTO, size=(64, 64), n_devices=1)
+    (line,) = M.gen_cache_info()
+    assert 'maray_jit' not in line and line.endswith('hint_mpixels 1'), line
+    # ... the same scene's kernels get built (another caller, an earlier run: here a context made for the purpose) ...
+    tape = s.lower()
+    M.Context(tape, backend=M.BACKEND_JIT).close()
+    assert tape.jit_code_cached
+    # ... and the next, larger call re-decides instead of rendering 16 Mpixels on the thumbnail's interpreter (by AUTO's own
+    # estimates cached kernels pay from ~9 Mpixels of this scene: a context of theirs costs 20 ms more than the interpreter's)
+    big = M.gen_to_image(s, backend=M.BACKEND_AUTO, size=(4096, 4096), n_devices=1)
+    (line,) = M.gen_cache_info()
+    assert 'kernel maray_jit_pixels' in line, line
+    assert np.array_equal(big[:1024, :2048], b) and np.array_equal(small, b[:64, :64])
+    again = M.gen_to_image(s, backend=M.BACKEND_AUTO, size=(64, 64), n_devices=1)      # a smaller call keeps the better context
+    (line,) = M.gen_cache_info()
+    assert 'kernel maray_jit_pixels' in line and np.array_equal(again, small)
+    M.gen_cache_clear()
+
+
+_BENCH_TWO_RANKS = ['--gpus', '2', '--steps', '5', '--warmup', '2', '--long-steps', '100', '--no-cold', '--cpu-seconds', '0']
+
+
+def test_bench_starts_two_ranks_on_the_devices_present():
+    """`python bench.py --gpus 2` as the driver issues it -- no torchrun around it: the parent starts two ranks (fresh
+    processes, never an exec of a process that touched the GPU), relays rank 0's line and its exit code.  On a one-GPU box the
+    two ranks share the device (a rehearsal: gloo for the barrier and the max, said so in the line); on two GPUs it is the
+    real thing over RCCL.  The line must say n_gpus 2, carry config 4 beside the weak-scaling headline, and both must
+    have checked their pixels against the golden hashes.  Rows are independent: /root/reference/src/render.rs:85-97."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MARAY_BENCH_FAKE_WORLD')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + _BENCH_TWO_RANKS, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['steps'] == 5 and j['value'] > 0
+    assert j['config']['pixels_per_step'] == 2 * 4096 * 4096 and j['config']['bit_exact_vs_golden'] is True
+    c4 = j['config4_strong']
+    assert c4 and c4['pixels_per_step'] == 16384 * 16384 and c4['rows_per_rank'] == 8192 and c4['bit_exact_vs_golden'] is True
+    assert j['long_loop']['steps'] == 100 and j['long_loop']['value'] > 0
+    assert (j['rehearsal'] is not None) == (M.device_count() < 2)
+    assert j['roofline']['attainable_peak']['value'] > 1000         # GB/s: this box's fill rate, measured in the run
+
+
 def test_gen_to_image_on_two_devices(chess_bytes):
     """Row tiles dealt to two devices, host-side gather into one raster (no collective).  Needs two
     GPUs: skips itself on a one-GPU box."""
