@@ -163,6 +163,24 @@ MARAY_DEV double mr_app(const MarayTex *tex, unsigned id, double x, double y)
     if (xi >= t.w || yi >= t.h) return 0.0;          // :34
     return (double)t.rgb[((size_t)yi * t.w + xi) * 3u + sel];  // :35
 }
+// The three channels of one texel (the specialised kernels, jit_emit.hpp): a scene samples a texture as
+// App(channel(i, 0), u, v), App(channel(i, 1), u, v), App(channel(i, 2), u, v) (examples/test6.rs:5-10), three calls of
+// fun_color_channel with the same coordinates.  The coordinate tests, the two casts and the address are the same for the
+// three: done once (mr_texel), and a channel is one byte load off that address (mr_texch).  No early return: a lane
+// outside the image reads a byte that is certainly there (`safe`: the descriptor table) and selects 0.0 -- the byte loads of
+// a wavefront issue back to back instead of behind two divergent branches each.
+typedef const __attribute__((address_space(1))) unsigned char *mr_gbytes;      // global memory, said so: global_load, not flat_load
+struct mr_tx { mr_gbytes p; bool ok; };
+MARAY_DEV mr_tx mr_texel(const MarayTex &t, const void *safe, double x, double y)
+{
+    const unsigned xi = mr_cast_u32(x), yi = mr_cast_u32(y);                       // src/textures.rs:32-33
+    mr_tx r;
+    r.ok = !(x < 0.0) & !(y < 0.0) & (xi < t.w) & (yi < t.h);                     // :30, :34 (a NaN coordinate is not < 0: it casts to 0)
+    r.p = r.ok ? (mr_gbytes)t.rgb + ((size_t)yi * t.w + xi) * 3u : (mr_gbytes)safe;
+    return r;
+}
+MARAY_DEV double mr_texch(const mr_tx &t, unsigned sel) { const unsigned b = t.p[sel]; return t.ok ? (double)b : 0.0; }   // :35
+
 // fun_image_width / fun_image_height (src/textures.rs:40-50).
 MARAY_DEV double mr_texdim(const MarayTex *tex, unsigned id)
 {
@@ -224,6 +242,14 @@ MARAY_DEV mr_d mr_stepsin_fast(const mr_d &v, float *defer)
 }
 MARAY_DEV mr_d mr_max(const mr_d &x, const mr_d &y) { return mr_d(mr_max(x.a, y.a), mr_max(x.b, y.b), mr_max(x.c, y.c), mr_max(x.d, y.d)); }
 MARAY_DEV mr_d mr_min(const mr_d &x, const mr_d &y) { return mr_d(mr_min(x.a, y.a), mr_min(x.b, y.b), mr_min(x.c, y.c), mr_min(x.d, y.d)); }
+struct mr_tx4 { mr_tx a, b, c, d; };
+MARAY_DEV mr_tx4 mr_texel(const MarayTex &t, const void *safe, const mr_d &x, const mr_d &y)
+{
+    mr_tx4 r;
+    r.a = mr_texel(t, safe, x.a, y.a); r.b = mr_texel(t, safe, x.b, y.b); r.c = mr_texel(t, safe, x.c, y.c); r.d = mr_texel(t, safe, x.d, y.d);
+    return r;
+}
+MARAY_DEV mr_d mr_texch(const mr_tx4 &t, unsigned sel) { return mr_d(mr_texch(t.a, sel), mr_texch(t.b, sel), mr_texch(t.c, sel), mr_texch(t.d, sel)); }
 MARAY_DEV mr_d mr_app(const MarayTex *tex, unsigned id, const mr_d &x, const mr_d &y)
 {
     return mr_d(mr_app(tex, id, x.a, y.a), mr_app(tex, id, x.b, y.b), mr_app(tex, id, x.c, y.c), mr_app(tex, id, x.d, y.d));

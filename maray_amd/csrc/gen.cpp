@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "backend.hpp"
+#include "host_pipe.hpp"
 #include "lower.hpp"
 #include "maray_hip.h"
 
@@ -65,9 +66,12 @@ struct Progress {
 
 // Pins the caller's raster for the time of a render unless it is pinned already; a raster that cannot be pinned
 // (registration refused, or too small to be worth a system call) is filled through the contexts' staging rings.
+// Registering costs 2.4 ms per 48 MiB the first time the library sees a range and ~0.1 ms every later time (measured:
+// pageable calls 3.4 ms, then 1.0-1.2 ms against 1.03 into memory that stays pinned), so the registration is NOT kept
+// between calls: it would save a tenth of a millisecond and leave a DMA target behind in memory the caller may free.
 struct ScopedPin {
     void *p = nullptr;
-    ScopedPin(uint8_t *raster, size_t bytes) {
+    void pin(uint8_t *raster, size_t bytes) {
         const char *e = getenv("MARAY_GEN_REGISTER");                 // "0": never register (measurement knob)
         if ((e && e[0] == '0') || bytes < ((size_t)4 << 20) || host_range_is_pinned(raster, bytes)) return;
         try { host_register(raster, bytes); p = raster; } catch (const Error &) {}
@@ -231,18 +235,6 @@ extern "C" int maray_gen_to_image(const maray_scene *s, const maray_texture *tex
         snprintf(buf, sizeof buf, "%016llx%016llx/%u/%u", (unsigned long long)h[0], (unsigned long long)h[1], n_tex, opts ? opts->backend : (uint32_t)MARAY_BACKEND_AUTO);
         key = buf;
     }
-    std::shared_ptr<GenEntry> entry = gen_cache_find(key);
-    if (!entry) {
-        maray_tape *tape = nullptr;
-        int rc = maray_lower(s, nullptr, &tape);
-        if (rc) return rc;
-        auto fresh = std::make_shared<GenEntry>();
-        fresh->key = key; fresh->tape = tape;
-        entry = gen_cache_insert(fresh);
-    }
-    maray_program prog;
-    maray_tape_program(entry->tape, &prog);
-
     int n_dev_avail = 0;
     maray_hip_device_count(&n_dev_avail);
     uint32_t n_dev = opts && opts->n_devices ? opts->n_devices : (uint32_t)(n_dev_avail > 0 ? n_dev_avail : 1);
@@ -272,12 +264,40 @@ extern "C" int maray_gen_to_image(const maray_scene *s, const maray_texture *tex
             share[k % n_dev].push_back((uint32_t)std::min<uint64_t>(h, y + tile_rows));
         }
     }
+    auto device_of = [&](uint32_t d) { return wrap ? (int)(d % (uint32_t)n_dev_avail) : (int)d; };
+
+    // The program of this call: remembered from an earlier one, or lowered now.  A first call's set-up is two things that do
+    // not depend on each other -- the lowering (host arithmetic: 20 ms for chess) and what a render needs from the device
+    // whatever the program is (streams, events, the copy stream, the tiles' device slots, the raster's pages pinned: 10-15 ms
+    // of driver calls) -- so the second runs on threads of its own while this one lowers (the reference compiles its three
+    // modules on every thread of every call, src/render.rs:158-165).
+    ScopedPin pin;
+    std::shared_ptr<GenEntry> entry = gen_cache_find(key);
+    if (!entry) {
+        std::vector<std::thread> warm;
+        struct Joiner { std::vector<std::thread> &v; ~Joiner() { for (auto &t : v) if (t.joinable()) t.join(); } } joiner{warm};
+        if (n_dev_avail > 0) {
+            warm.emplace_back([&] { pin.pin(rgb8, (size_t)w * h * 3); });
+            for (uint32_t d = 0; d < n_dev; d++)
+                warm.emplace_back(host_pipe_prewarm, device_of(d), w, std::min(tile_rows, h), (int)std::min<size_t>(3, share[d].size() / 2));
+        }
+        maray_tape *tape = nullptr;
+        const int rc = maray_lower(s, nullptr, &tape);
+        for (auto &t : warm) t.join();
+        warm.clear();
+        if (rc) return rc;
+        auto fresh = std::make_shared<GenEntry>();
+        fresh->key = key; fresh->tape = tape;
+        entry = gen_cache_insert(fresh);
+    } else pin.pin(rgb8, (size_t)w * h * 3);
+    maray_program prog;
+    maray_tape_program(entry->tape, &prog);
+
     maray_ctx_opts co;
     memset(&co, 0, sizeof co);
     co.backend = opts ? opts->backend : MARAY_BACKEND_AUTO;
     co.hint_mpixels = (uint32_t)std::min<uint64_t>(0xFFFFFFFFu, (((uint64_t)w * h / n_dev) >> 20) + 1);
 
-    ScopedPin pin(rgb8, (size_t)w * h * 3);
     Progress P;
     struct TileUser { Progress *P; };
     TileUser tu{&P};
@@ -291,7 +311,7 @@ extern "C" int maray_gen_to_image(const maray_scene *s, const maray_texture *tex
     };
     auto worker = [&](uint32_t d) {
         // worker d's context: the one an earlier call left (same program, same worker slot), or a new one
-        const int dev = wrap ? (int)(d % (uint32_t)n_dev_avail) : (int)d;
+        const int dev = device_of(d);
         const IdleCtx kept = gen_cache_take(*entry, dev, co.backend == MARAY_BACKEND_AUTO, co.hint_mpixels);
         maray_ctx *ctx = kept.ctx;
         int r = ctx ? MARAY_OK : maray_hip_ctx_create(dev, &prog, tex, n_tex, &co, &ctx);

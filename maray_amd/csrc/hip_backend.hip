@@ -612,7 +612,7 @@ struct TapeBackend final : Backend {
     uint32_t n_row_jobs = 0;
     uint32_t xrows_slot = 0, xguards_slot = 0;
     unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;      // time_rows without a caller's buffer
-    HostPipe pipe;                      // streams + staging of the host-raster entry points
+    std::unique_ptr<HostPipe> pipe;     // streams + staging of the host-raster entry points (from the device's pool: host_pipe.hpp)
     hipStream_t own_stream = nullptr;   // = pipe's compute stream
     hipStream_t last_stream = nullptr; bool have_last = false;      // the stream of the last launch (see launch())
     hipEvent_t handover = nullptr;
@@ -631,6 +631,7 @@ struct TapeBackend final : Backend {
         (void)hipFree(d_xtape_bits); (void)hipFree(d_xtape_rows); (void)hipFree(d_xrows); (void)hipFree(d_xguards);
         (void)hipFree(d_row_job_off); (void)hipFree(d_row_job_len); (void)hipFree(d_job_id); (void)hipFree(d_queue);
         if (handover) (void)hipEventDestroy(handover);
+        if (pipe) { (void)hipStreamSynchronize(pipe->compute_stream()); host_pipe_release(std::move(pipe)); }
     }
 
     void init(int dev, const maray_program &prog, const maray_texture *tex, uint32_t n_tex, bool lds_variant) {
@@ -641,8 +642,8 @@ struct TapeBackend final : Backend {
             throw Error{MARAY_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only"};
         P = prog;
         P.consts = nullptr; P.row_ops = nullptr; P.pix_ops = nullptr;   // host pointers are borrowed for this call only
-        pipe.init(dev);
-        own_stream = pipe.compute_stream();
+        pipe = host_pipe_acquire(dev);
+        own_stream = pipe->compute_stream();
         HIP_TRY(hipEventCreateWithFlags(&handover, hipEventDisableTiming));
         auto up = [&](const void *src, size_t bytes, void **dst) {
             HIP_TRY(hipMalloc(dst, bytes ? bytes : 8));
@@ -900,7 +901,7 @@ struct TapeBackend final : Backend {
     void render_host_tiles(uint32_t w, uint32_t, const std::vector<RowTile> &tiles, uint32_t row0, uint8_t *rgb8, double *rgb64,
                            const std::function<void(uint32_t, uint32_t)> &done) override {
         HIP_TRY(hipSetDevice(device));
-        pipe.run(w, tiles, row0, rgb8, rgb64,
+        pipe->run(w, tiles, row0, rgb8, rgb64,
                  [&](const RowBlocks &rb, unsigned char *d8, double *d64, hipStream_t st) { launch(w, rb, d8, d64, st, true); }, done);
     }
 

@@ -4,6 +4,8 @@
 
 #include <algorithm>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 
 namespace maray {
@@ -70,6 +72,68 @@ void HostPipe::init(int dev)
         HIP_TRY(hipEventCreateWithFlags(&kernels_done[s], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&copy_done[s], hipEventDisableTiming));
     }
+}
+
+void HostPipe::reserve(uint32_t w, uint32_t tile_rows, int n_slots)
+{
+    HIP_TRY(hipSetDevice(device));
+    if (!copy) HIP_TRY(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+    const size_t bytes = (size_t)w * tile_rows * 3;
+    for (int s = 0; s < std::min(n_slots, (int)SLOTS); s++) {
+        if (d8_cap[s] >= bytes) continue;
+        if (d8[s]) HIP_TRY(hipFree(d8[s]));
+        d8[s] = nullptr; d8_cap[s] = 0;
+        HIP_TRY(hipMalloc((void **)&d8[s], bytes));
+        d8_cap[s] = bytes;
+    }
+}
+
+void HostPipe::trim()
+{
+    (void)hipSetDevice(device);
+    for (int s = 0; s < SLOTS; s++) {
+        if (d64[s]) { (void)hipFree(d64[s]); d64[s] = nullptr; d64_cap[s] = 0; }
+        if (ring[s]) { (void)hipHostFree(ring[s]); ring[s] = nullptr; ring_cap[s] = 0; }
+        if (d8_cap[s] > ((size_t)64 << 20)) { (void)hipFree(d8[s]); d8[s] = nullptr; d8_cap[s] = 0; }      // (an unusually large tile)
+    }
+}
+
+namespace {
+std::mutex g_pool_mutex;
+// never destroyed: at process exit the HIP runtime may be gone before a static's destructor runs
+std::multimap<int, std::unique_ptr<HostPipe>> &g_pool = *new std::multimap<int, std::unique_ptr<HostPipe>>();
+}   // namespace
+
+std::unique_ptr<HostPipe> host_pipe_acquire(int device)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        auto it = g_pool.find(device);
+        if (it != g_pool.end()) { std::unique_ptr<HostPipe> p = std::move(it->second); g_pool.erase(it); return p; }
+    }
+    std::unique_ptr<HostPipe> p(new HostPipe());
+    p->init(device);
+    return p;
+}
+
+void host_pipe_release(std::unique_ptr<HostPipe> p) noexcept
+{
+    if (!p) return;
+    p->trim();
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        if (g_pool.count(p->device_index()) < 4) { const int d = p->device_index(); g_pool.emplace(d, std::move(p)); return; }
+    }
+    p.reset();          // (outside the lock: streams are destroyed)
+}
+
+void host_pipe_prewarm(int device, uint32_t w, uint32_t tile_rows, int n_slots) noexcept
+{
+    try {
+        std::unique_ptr<HostPipe> p = host_pipe_acquire(device);
+        try { p->reserve(w, tile_rows, n_slots); } catch (const Error &) {}
+        host_pipe_release(std::move(p));
+    } catch (...) {}
 }
 
 std::vector<RowTile> cut_row_tiles(uint32_t w, uint32_t y0, uint32_t y1, bool want8, bool want64)

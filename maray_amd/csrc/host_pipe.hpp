@@ -18,6 +18,7 @@
 
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <vector>
 
 #include "backend.hpp"
@@ -36,6 +37,11 @@ public:
     ~HostPipe();
     void init(int device);
     hipStream_t compute_stream() const { return compute; }
+    int device_index() const { return device; }
+    // what the first run() of a w-pixel-wide image with tiles of `tile_rows` rows would create: the copy stream and the
+    // device slots (RGB8).  Done ahead of time by host_pipe_prewarm, on another thread than the one that lowers the scene.
+    void reserve(uint32_t w, uint32_t tile_rows, int n_slots);
+    void trim();        // frees the f64 slots and the pinned ring (8x and 1x an RGB8 slot): what an idle pipe in the pool does not keep
 
     // Renders `tiles` (row ranges of a w-pixel-wide image) in order.  rgb8 / rgb64 point at the
     // first byte of image row `row0` of the caller's rasters (either may be null).
@@ -53,5 +59,13 @@ private:
     void *ring[SLOTS] = {};             // pinned staging, pageable destinations only
     size_t ring_cap[SLOTS] = {};
 };
+
+// Pipes outlive contexts: a pipe's streams, events and device slots do not depend on the program, and creating them is a
+// third of what a context costs (3.6 ms of streams and events at creation, a copy stream and two or three hipMalloc of
+// 24 MiB on the first frame).  A context takes its pipe from a per-device pool and gives it back when it is freed;
+// host_pipe_prewarm fills the pool from another thread while the caller is still lowering its scene (gen.cpp).
+std::unique_ptr<HostPipe> host_pipe_acquire(int device);             // throws Error
+void host_pipe_release(std::unique_ptr<HostPipe> p) noexcept;         // (at most 4 idle pipes per device are kept)
+void host_pipe_prewarm(int device, uint32_t w, uint32_t tile_rows, int n_slots) noexcept;      // errors are left for the context to find
 
 }   // namespace maray

@@ -54,7 +54,7 @@ struct JitBackend final : Backend {
     double *d_yvals = nullptr; size_t yvals_cap = 0;          // ROW-stage tables (the context's, not a launch's: launches are ordered by their stream)
     unsigned long long *d_gbits = nullptr; size_t gbits_cap = 0;
     unsigned char *d_rgb8 = nullptr; size_t rgb8_cap = 0;      // time_rows without a caller's buffer
-    HostPipe pipe;                      // streams + staging of the host-raster entry points
+    std::unique_ptr<HostPipe> pipe;     // streams + staging of the host-raster entry points (from the device's pool: host_pipe.hpp)
     hipStream_t own_stream = nullptr;   // = pipe's compute stream
     uint32_t n_row_chunks = 1, n_gwords = 0, n_gjobs = 0, guard_rows = 1, guard_sub = 1;       // guard_sub: guard rectangles per 256-pixel tile
     uint32_t n_cu = 256;
@@ -75,6 +75,7 @@ struct JitBackend final : Backend {
         (void)hipFree(d_order); (void)hipFree(d_rgb8);
         (void)hipFree(d_yvals); (void)hipFree(d_gbits);
         if (handover) (void)hipEventDestroy(handover);
+        if (pipe) { (void)hipStreamSynchronize(pipe->compute_stream()); host_pipe_release(std::move(pipe)); }
     }
 
     void init(int dev, const maray_program &prog, const maray_texture *tex, uint32_t n_tex) {
@@ -130,9 +131,9 @@ struct JitBackend final : Backend {
             lap("load ROW module");
 
         }
-        pipe.init(dev);
+        pipe = host_pipe_acquire(dev);
         lap("host pipe");
-        own_stream = pipe.compute_stream();
+        own_stream = pipe->compute_stream();
         HIP_TRY(hipEventCreateWithFlags(&handover, hipEventDisableTiming));
         std::vector<DevTex> descs(n_tex ? n_tex : 1);
         for (uint32_t i = 0; i < n_tex; i++) {
@@ -263,7 +264,7 @@ struct JitBackend final : Backend {
     void render_host_tiles(uint32_t w, uint32_t, const std::vector<RowTile> &tiles, uint32_t row0, uint8_t *rgb8, double *rgb64,
                            const std::function<void(uint32_t, uint32_t)> &done) override {
         HIP_TRY(hipSetDevice(device));
-        pipe.run(w, tiles, row0, rgb8, rgb64,
+        pipe->run(w, tiles, row0, rgb8, rgb64,
                  [&](const RowBlocks &rb, unsigned char *d8, double *d64, hipStream_t st) { launch(w, rb, d8, d64, st, true); }, done);
     }
 

@@ -263,6 +263,8 @@ struct Emitter {
     std::string td = "double", tm = "mr_mask";  // types of a value / a boolean in the generated text ("mr_d" / "mr_m": four pixels per lane)
     std::vector<double> ktab_vals;
     std::unordered_map<uint64_t, uint32_t> ktab_block;
+    bool texel_once = false;                    // PIXEL: App ops of one image on the same coordinates share one mr_texel (descriptors mr_t<image> in scope)
+    std::map<std::string, std::pair<std::string, uint32_t>> texels;      // (image, x, y, width) -> its variable and the block it was declared in
     const RedPlan *rplan = nullptr;             // PIXEL: the guarded OR-reductions of the section being emitted (null: walk the tree as written)
     uint32_t red_serial = 0;                    // (names of the labels: a section may be emitted more than once into one kernel)
     explicit Emitter(const maray_program &p) : P(p) {}
@@ -285,6 +287,7 @@ struct Emitter {
     void section(const uint64_t *ops, uint32_t n, uint32_t n_slots, bool pixel, const char *prefix)
     {
         vals.assign(n, Val());
+        texels.clear();
         is_bool_op.assign(n, 0);
         std::vector<int> slot(n_slots, -1);
         int acc = -1;
@@ -565,7 +568,23 @@ struct Emitter {
                 break;
             case MARAY_OP_EXP: e = "mr_exp(" + dbl(va, "m", i, 0) + ")"; break;
             case MARAY_OP_LN: e = "mr_ln(" + dbl(va, "m", i, 0) + ")"; break;
-            case MARAY_OP_APP: e = "mr_app(tex, " + std::to_string(aux) + "u, " + dbl(va, "m", i, 0) + ", " + dbl(vb, "m", i, 1) + ")"; break;
+            case MARAY_OP_APP: {
+                const std::string ax = dbl(va, "m", i, 0), ay = dbl(vb, "m", i, 1);
+                if (!(pixel && texel_once)) { e = "mr_app(tex, " + std::to_string(aux) + "u, " + ax + ", " + ay + ")"; break; }
+                // one texel, three channels: the coordinate work and the address are shared by the App ops of one image on the
+                // same two operands (device_math.h, mr_texel); the texel's variable is reused while its block is open
+                const std::string key = std::to_string(aux / 5u) + "|" + ax + "|" + ay + "|" + td;
+                auto it = texels.find(key);
+                bool in_scope = false;
+                if (it != texels.end()) { in_scope = it->second.second == 0; for (const Open &o : open) in_scope |= o.id == it->second.second; }
+                if (!in_scope) {
+                    const std::string tn = "mr_tx" + std::to_string(i);
+                    out += "    const " + std::string(td == "mr_d" ? "mr_tx4 " : "mr_tx ") + tn + " = mr_texel(mr_t" + std::to_string(aux / 5u) + ", tex, " + ax + ", " + ay + ");\n";
+                    it = texels.insert_or_assign(key, std::make_pair(tn, open.empty() ? 0u : open.back().id)).first;
+                }
+                e = "mr_texch(" + it->second.first + ", " + std::to_string(aux % 5u) + "u)";
+                break;
+            }
             case MARAY_OP_TEXDIM: e = "mr_texdim(tex, " + std::to_string(aux) + "u)"; break;
             default: throw Error{MARAY_E_ARG, "invalid opcode"};
             }

@@ -451,6 +451,16 @@ std::string jit_source(const maray_program &P, int min_waves)
          "    // -> image row (RowBlocks); one range of rows (blk_stride == 0) needs no division, and yrows is a power of two\n"
          "    const double Y = (double)(blk_stride == 0u ? y0 + row_base + r : y0 + ((row_base + r) / blk_rows) * blk_stride + (row_base + r) % blk_rows);\n"
          "    (void)Y; (void)tex; (void)gbits; (void)yrows; (void)tile_list; (void)tile_base;\n";
+    {   // the descriptors of the textures the section samples: scalar loads, once per wavefront
+        std::vector<uint8_t> used;
+        for (uint32_t i = 0; i < P.n_pix_ops; i++)
+            if (MARAY_INS_OP(P.pix_ops[i]) == MARAY_OP_APP) { const uint32_t img = MARAY_INS_AUX(P.pix_ops[i]) / 5u; if (used.size() <= img) used.resize(img + 1, 0); used[img] = 1; }
+        const char *e_ = getenv("MARAY_JIT_TEXEL_ONCE");           // "0": a call of mr_app per App op (= round 3; ablation)
+        E.texel_once = !used.empty() && !(e_ && e_[0] == '0');
+        if (E.texel_once)
+            for (size_t img = 0; img < used.size(); img++)
+                if (used[img]) s += "    const MarayTex mr_t" + std::to_string(img) + " = tex[" + std::to_string(img) + "];\n";
+    }
     if (n_gwords)
         s += "    const unsigned long long mr_gbase0 = (unsigned long long)(gbits + ((size_t)((row_base + r) >> __builtin_ctz(yrows)) * n_tx + tile0) * " + tw + "u);\n";
     if (gw_vgpr)

@@ -25,7 +25,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <exception>
 #include <functional>
+#include <pthread.h>
 #include <unordered_map>
 #include <unordered_set>
 
@@ -1335,16 +1337,59 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         if (k > MARAY_MAX_INDEX + 1) throw Error{MARAY_E_LIMIT, "more than 16384 row values"};
     }
     lap("typing, dry schedule");
-    L.in_section = is_row;
-    L.build(row, false);
-    lap("ROW section");
-
     std::vector<uint8_t> is_pix(N, 0);
     for (size_t i = 0; i < N; i++) if (reach[i] && is_op((int32_t)i) && !is_row[i]) is_pix[i] = 1;
     for (int c = 0; c < 3; c++) pix.outs.push_back({roots[c], (uint32_t)c});
-    L.in_section = is_pix;
-    L.build(pix, true);
-    lap("PIXEL section");
+    // The two sections are scheduled side by side (each is a third of a large scene's lowering; a first render call is
+    // as long as its lowering): the ROW section on a copy of the scheduler, on a thread of its own.  What they share is
+    // the constant pool, in which the ROW section's constants come first: the PIXEL section numbers its new constants
+    // from the pool as it stood before either, and is renumbered once the ROW section's are known -- the tape is the one
+    // the sections give one after the other (MARAY_LOWER_SERIAL=1 does that; a CPU test compares the two).
+    const char *serial = getenv("MARAY_LOWER_SERIAL");
+    if ((serial && serial[0] == '1') || row.outs.size() + (size_t)std::count(is_row.begin(), is_row.end(), 1) < 2000) {
+        L.in_section = is_row;
+        L.build(row, false);
+        lap("ROW section");
+        L.in_section = is_pix;
+        L.build(pix, true);
+        lap("PIXEL section");
+    } else {
+        const size_t base = L.consts.size();
+        Lowerer LR = L;
+        // (a thread with the stack the scheduler's recursion needs: this function itself runs on one of 1 GiB, api.cpp)
+        struct RowJob {
+            Lowerer &LR; Section &row; const std::vector<uint8_t> &is_row; std::exception_ptr error;
+            static void *main(void *p) {
+                RowJob *j = (RowJob *)p;
+                try { j->LR.in_section = j->is_row; j->LR.build(j->row, false); } catch (...) { j->error = std::current_exception(); }
+                return nullptr;
+            }
+        } job{LR, row, is_row, nullptr};
+        pthread_attr_t at;
+        pthread_attr_init(&at);
+        pthread_attr_setstacksize(&at, (size_t)1 << 30);
+        pthread_t th;
+        const bool threaded = pthread_create(&th, &at, RowJob::main, &job) == 0;
+        pthread_attr_destroy(&at);
+        struct Join { pthread_t &t; bool on; ~Join() { if (on) pthread_join(t, nullptr); } } join{th, threaded};
+        if (!threaded) RowJob::main(&job);
+        L.in_section = is_pix;
+        L.build(pix, true);
+        if (threaded) { pthread_join(th, nullptr); join.on = false; }
+        if (job.error) std::rethrow_exception(job.error);
+        // pool = [before | ROW's new | PIXEL's new that the ROW section did not bring]
+        std::vector<uint32_t> remap(L.consts.size());
+        for (size_t i = 0; i < L.consts.size(); i++) remap[i] = i < base ? (uint32_t)i : LR.const_ref(L.consts[i]);
+        auto fix = [&](uint32_t r) { return MARAY_REF_KIND(r) == MARAY_K_CONST ? MARAY_REF(MARAY_K_CONST, remap[MARAY_REF_INDEX(r)]) : r; };
+        for (uint64_t &ins : pix.ops) {
+            const uint32_t op = MARAY_INS_OP(ins);
+            if (op == MARAY_OP_NOP || op == MARAY_OP_TEXDIM) continue;
+            const bool binary = op >= MARAY_OP_ADD && op <= MARAY_OP_APP;
+            ins = MARAY_INS(op, MARAY_INS_AUX(ins), MARAY_INS_DST(ins), fix(MARAY_INS_A(ins)), binary ? fix(MARAY_INS_B(ins)) : MARAY_INS_B(ins));
+        }
+        L.consts = std::move(LR.consts);
+        lap("ROW and PIXEL sections");
+    }
 
     t.consts = std::move(L.consts);
     if (t.consts.empty()) t.consts.push_back(0.0);

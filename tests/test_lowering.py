@@ -297,3 +297,19 @@ def test_rescheduled_cones_of_random_shapes_keep_every_value(seed, n, mixed):
             for k in range(first, min(first + 8, info['n_yvals'])):
                 if full[k] is None: continue
                 assert part[k] is not None and same_f64(part[k], full[k]), (first, k, honor)
+
+
+def test_sections_scheduled_side_by_side_give_the_serial_tape(chess_bytes, monkeypatch):
+    """Large programs schedule their ROW and PIXEL sections on two threads (lower.cpp); the constant pool is merged so that
+    the tape is, bit for bit, the one the sections give one after the other (MARAY_LOWER_SERIAL=1)."""
+    from fuzz_scenes import curved_soup, polygon_soup
+    scn = [chess_bytes, encode((1024, 200), polygon_soup(11, 70, 1024, 200, mixed=False)), encode((1024, 200), curved_soup(401, 60, 1024, 200, mixed='colours'))]
+    for data in scn:
+        s = M.Scene(data)
+        monkeypatch.setenv('MARAY_LOWER_SERIAL', '1')
+        a = s.lower()
+        monkeypatch.setenv('MARAY_LOWER_SERIAL', '0')
+        b = s.lower()
+        assert a.info == b.info and a.info['n_row_ops'] + a.info['n_pix_ops'] > 2000
+        for x, y in zip(a.arrays(), b.arrays()):
+            assert np.array_equal(x.view(np.uint64), y.view(np.uint64))
