@@ -65,6 +65,7 @@ struct JitCode {
     std::vector<char> pix, rows;        // maray_jit_pixels; maray_jit_rows + maray_jit_order (empty without a ROW section)
     uint32_t n_row_chunks = 1, n_gjobs = 0;
     uint32_t n_gwords = 0, guard_w = 256, guard_h = 1;      // guard words per rectangle and the rectangle they are bounded over (what the sources were generated for)
+    bool rows2 = false;                 // the PIXEL kernel's busy tiles take two rows per wavefront (jit_rows2): launches may pass rpw = 2
     int waves = 8;                      // the __launch_bounds__ occupancy the PIXEL kernel was built for
     bool from_disk = false;
 };

@@ -84,6 +84,8 @@ MARAY_DEV double mr_ln(double a) { return maray_libm_log(a); }
 
 // value -> lane mask, and the one test a region needs: is any lane's bit set
 MARAY_DEV mr_mask mr_ge0(double a) { return mr_ballot(a >= 0.0); }       // Step
+MARAY_DEV mr_mask mr_gek(double a, double k) { return mr_ballot(a >= k); }      // Step(a + (-k)), see jit_emit.hpp
+MARAY_DEV mr_mask mr_lek(double a, double k) { return mr_ballot(a <= k); }      // Step(-(a + (-k)))
 MARAY_DEV mr_mask mr_ne0(double a) { return mr_ballot(a != 0.0); }
 MARAY_DEV mr_mask mr_ne1(double a) { return mr_ballot(a != 1.0); }
 MARAY_DEV mr_mask mr_stepsin_bounded_m(double a) { return mr_ballot(maray_libm_step_sin_bounded(a) != 0.0); }
@@ -189,6 +191,68 @@ MARAY_DEV double mr_texdim(const MarayTex *tex, unsigned id)
 }
 
 #ifdef MR_VEC4
+// ---- two rows per lane (the specialised PIXEL kernel's busy tiles) ------------------------------------------------
+// A wavefront that owns the same 64 pixels of two neighbouring rows of one guard rectangle enters the same shapes for
+// both (one set of guard bits covers the rectangle's 32 rows): the branch-table dispatch, the shape's constants
+// (scalar loads and their waits) and everything that depends on x alone are paid once for 128 pixels.  A value that
+// depends on the row -- it read Y or a y value somewhere -- is a pair (mr_p: .a = row r, .b = row r + 1), a boolean
+// a pair of lane masks (mr_pm); values of x and constants alone stay single and widen where an operation mixes them
+// (the converting constructors).  The generated text is the same as for one row; the emitter types each variable.
+struct mr_p {
+    double a, b;
+    MARAY_DEV mr_p() {}
+    MARAY_DEV mr_p(double s) : a(s), b(s) {}
+    MARAY_DEV mr_p(double a_, double b_) : a(a_), b(b_) {}
+};
+struct mr_pm {
+    mr_mask a, b;
+    MARAY_DEV mr_pm() {}
+    MARAY_DEV mr_pm(mr_mask s) : a(s), b(s) {}
+    MARAY_DEV mr_pm(mr_mask a_, mr_mask b_) : a(a_), b(b_) {}
+};
+#define MR_PAIR1(f, v) mr_p(f((v).a), f((v).b))
+MARAY_DEV mr_p operator+(const mr_p &x, const mr_p &y) { return mr_p(x.a + y.a, x.b + y.b); }
+MARAY_DEV mr_p operator*(const mr_p &x, const mr_p &y) { return mr_p(x.a * y.a, x.b * y.b); }
+MARAY_DEV mr_pm operator&(const mr_pm &x, const mr_pm &y) { return mr_pm(x.a & y.a, x.b & y.b); }
+MARAY_DEV mr_pm operator|(const mr_pm &x, const mr_pm &y) { return mr_pm(x.a | y.a, x.b | y.b); }
+MARAY_DEV mr_pm &operator|=(mr_pm &x, const mr_pm &y) { x.a |= y.a; x.b |= y.b; return x; }
+MARAY_DEV mr_pm operator~(const mr_pm &x) { return mr_pm(~x.a, ~x.b); }
+MARAY_DEV bool mr_any(const mr_pm &m) { return (m.a | m.b) != MR_NONE; }
+MARAY_DEV bool mr_covered(mr_mask m) { return m == MR_ALL; }                       // every lane has its 1: a reduction's OR may stop
+MARAY_DEV bool mr_covered(const mr_pm &m) { return (m.a & m.b) == MR_ALL; }
+MARAY_DEV mr_p mr_pos(const mr_pm &m) { return mr_p(mr_pos(m.a), mr_pos(m.b)); }
+MARAY_DEV mr_p mr_neg01(const mr_pm &m) { return mr_p(mr_neg01(m.a), mr_neg01(m.b)); }
+MARAY_DEV mr_p mr_sel0(const mr_pm &m, const mr_p &v) { return mr_p(mr_sel0(m.a, v.a), mr_sel0(m.b, v.b)); }
+MARAY_DEV mr_pm mr_ge0(const mr_p &v) { return mr_pm(mr_ge0(v.a), mr_ge0(v.b)); }
+MARAY_DEV mr_pm mr_gek(const mr_p &v, double k) { return mr_pm(mr_gek(v.a, k), mr_gek(v.b, k)); }
+MARAY_DEV mr_pm mr_lek(const mr_p &v, double k) { return mr_pm(mr_lek(v.a, k), mr_lek(v.b, k)); }
+MARAY_DEV mr_pm mr_ne0(const mr_p &v) { return mr_pm(mr_ne0(v.a), mr_ne0(v.b)); }
+MARAY_DEV mr_pm mr_ne1(const mr_p &v) { return mr_pm(mr_ne1(v.a), mr_ne1(v.b)); }
+MARAY_DEV mr_pm mr_stepsin_bounded_m(const mr_p &v) { return mr_pm(mr_stepsin_bounded_m(v.a), mr_stepsin_bounded_m(v.b)); }
+MARAY_DEV mr_pm mr_stepsin_bounded_mk(const mr_p &v, const __attribute__((address_space(4))) double *k) { return mr_pm(mr_stepsin_bounded_mk(v.a, k), mr_stepsin_bounded_mk(v.b, k)); }
+MARAY_DEV mr_p mr_stepsin_fast_k(const mr_p &v, float *defer, const __attribute__((address_space(4))) double *k) { return mr_p(mr_stepsin_fast_k(v.a, defer, k), mr_stepsin_fast_k(v.b, defer, k)); }
+MARAY_DEV mr_p mr_stepsin_fast(const mr_p &v, float *defer) { return mr_p(mr_stepsin_fast(v.a, defer), mr_stepsin_fast(v.b, defer)); }
+MARAY_DEV mr_p mr_stepsin(const mr_p &v) { return MR_PAIR1(mr_stepsin, v); }
+MARAY_DEV mr_p mr_neg(const mr_p &v) { return MR_PAIR1(mr_neg, v); }
+MARAY_DEV mr_p mr_abs(const mr_p &v) { return MR_PAIR1(mr_abs, v); }
+MARAY_DEV mr_p mr_recip(const mr_p &v) { return MR_PAIR1(mr_recip, v); }
+MARAY_DEV mr_p mr_sqrt(const mr_p &v) { return MR_PAIR1(mr_sqrt, v); }
+MARAY_DEV mr_p mr_sin(const mr_p &v) { return MR_PAIR1(mr_sin, v); }
+MARAY_DEV mr_p mr_sin_bounded(const mr_p &v) { return MR_PAIR1(mr_sin_bounded, v); }
+MARAY_DEV mr_p mr_exp(const mr_p &v) { return MR_PAIR1(mr_exp, v); }
+MARAY_DEV mr_p mr_ln(const mr_p &v) { return MR_PAIR1(mr_ln, v); }
+MARAY_DEV mr_p mr_max(const mr_p &x, const mr_p &y) { return mr_p(mr_max(x.a, y.a), mr_max(x.b, y.b)); }
+MARAY_DEV mr_p mr_min(const mr_p &x, const mr_p &y) { return mr_p(mr_min(x.a, y.a), mr_min(x.b, y.b)); }
+struct mr_tx2 { mr_tx a, b; };
+MARAY_DEV mr_tx2 mr_texel(const MarayTex &t, const void *safe, const mr_p &x, const mr_p &y)
+{
+    mr_tx2 r;
+    r.a = mr_texel(t, safe, x.a, y.a); r.b = mr_texel(t, safe, x.b, y.b);
+    return r;
+}
+MARAY_DEV mr_p mr_texch(const mr_tx2 &t, unsigned sel) { return mr_p(mr_texch(t.a, sel), mr_texch(t.b, sel)); }
+MARAY_DEV mr_p mr_app(const MarayTex *tex, unsigned id, const mr_p &x, const mr_p &y) { return mr_p(mr_app(tex, id, x.a, y.a), mr_app(tex, id, x.b, y.b)); }
+
 // ---- four pixels per lane (the specialised PIXEL kernel) --------------------------------------------------------
 // A wavefront owns a whole 256-pixel tile: every value is four f64 per lane (mr_d), every boolean four lane masks
 // (mr_m).  The scalar unit's work per tile -- guard-bit tests, region branches, constant and y-value loads -- is
@@ -219,6 +283,8 @@ MARAY_DEV mr_d mr_pos(const mr_m &m) { return mr_d(mr_pos(m.a), mr_pos(m.b), mr_
 MARAY_DEV mr_d mr_sel0(const mr_m &m, const mr_d &v) { return mr_d(mr_sel0(m.a, v.a), mr_sel0(m.b, v.b), mr_sel0(m.c, v.c), mr_sel0(m.d, v.d)); }
 MARAY_DEV mr_d mr_neg01(const mr_m &m) { return mr_d(mr_neg01(m.a), mr_neg01(m.b), mr_neg01(m.c), mr_neg01(m.d)); }
 MARAY_DEV mr_m mr_ge0(const mr_d &v) { return mr_m(mr_ge0(v.a), mr_ge0(v.b), mr_ge0(v.c), mr_ge0(v.d)); }
+MARAY_DEV mr_m mr_gek(const mr_d &v, double k) { return mr_m(mr_gek(v.a, k), mr_gek(v.b, k), mr_gek(v.c, k), mr_gek(v.d, k)); }
+MARAY_DEV mr_m mr_lek(const mr_d &v, double k) { return mr_m(mr_lek(v.a, k), mr_lek(v.b, k), mr_lek(v.c, k), mr_lek(v.d, k)); }
 MARAY_DEV mr_m mr_ne0(const mr_d &v) { return mr_m(mr_ne0(v.a), mr_ne0(v.b), mr_ne0(v.c), mr_ne0(v.d)); }
 MARAY_DEV mr_m mr_ne1(const mr_d &v) { return mr_m(mr_ne1(v.a), mr_ne1(v.b), mr_ne1(v.c), mr_ne1(v.d)); }
 MARAY_DEV mr_m mr_stepsin_bounded_m(const mr_d &v) { return mr_m(mr_stepsin_bounded_m(v.a), mr_stepsin_bounded_m(v.b), mr_stepsin_bounded_m(v.c), mr_stepsin_bounded_m(v.d)); }

@@ -59,6 +59,8 @@ struct JitBackend final : Backend {
     uint32_t n_row_chunks = 1, n_gwords = 0, n_gjobs = 0, guard_rows = 1, guard_sub = 1;       // guard_sub: guard rectangles per 256-pixel tile
     uint32_t n_cu = 256;
     bool wide_all = false;              // the whole section runs four pixels per lane (jit_wide_general)
+    bool rows2 = false;                 // busy tiles two rows per wavefront (JitCode::rows2)
+    bool rpw1 = false;                  // MARAY_RPW1=1 (measurement): a two-row kernel launched one row per wavefront
     unsigned k_tiles = 0;               // MARAY_JIT_TILES: tiles per wavefront (0 = by launch size), read once when the context is created
     bool has_sin = false;               // some Sin argument is not proven bounded: tiles may be deferred to `slow`
     hipStream_t last_stream = nullptr; bool have_last = false;      // the stream of the last launch (see launch())
@@ -118,6 +120,8 @@ struct JitBackend final : Backend {
         lap("load PIXEL module");
         n_row_chunks = code->n_row_chunks; n_gjobs = code->n_gjobs;
         wide_all = jit_wide_general(prog, code->n_gwords);
+        rows2 = code->rows2;
+        if (const char *e_ = getenv("MARAY_RPW1")) rpw1 = e_[0] == '1';
         if (has_sin) slow = make_tape_backend(dev, prog, tex, n_tex, false);     // drains the tiles the pixel kernel defers; other programs never defer
         P = prog;
         P.consts = nullptr; P.row_ops = nullptr; P.pix_ops = nullptr;
@@ -232,6 +236,10 @@ struct JitBackend final : Backend {
         const uint64_t device_slots = (uint64_t)n_cu * 4 * 7;
         unsigned tiles = wide_all ? (n_tiles <= device_slots ? 1 : n_tiles <= 4 * device_slots ? 2 : n_tiles <= 16 * device_slots ? 4 : 8)
                                   : (n_tiles <= 4 * device_slots ? 1 : n_tiles <= 16 * device_slots ? 2 : 4);
+        // two rows per wavefront: when the launch's guard groups have an even number of rows (a pair then lies inside one group);
+        // the strip is half as long, so that a wavefront owns as many pixels as it would with one row
+        const unsigned rpw = (rows2 && !rpw1 && yrows >= 2 && yrows % 2 == 0) ? 2u : 1u;
+        if (rpw == 2 && tiles > 1) tiles /= 2;
         if (k_tiles) tiles = std::min(64u, k_tiles);
         if (n_gwords && n_gwords <= GW_INLINE_MAX) tiles = std::min(tiles, 64u / (n_gwords * guard_sub));      // a strip's guard words: one per lane
         tiles = std::max(1u, std::min(tiles, n_tx));
@@ -241,8 +249,9 @@ struct JitBackend final : Backend {
             ensure(d_flags, flags_cap, (size_t)n_tiles + 1);                // work list {count, tile, ...} of deferred tiles
             HIP_TRY(hipMemsetAsync(d_flags, 0, sizeof(unsigned), st));
         }
-        for (uint32_t r0 = 0; r0 < rows_total; r0 += 65535) {          // gridDim.y limit
-            const uint32_t rows = std::min<uint32_t>(65535, rows_total - r0);
+        const uint32_t rows_per_grid = 65534u * rpw;                   // gridDim.y limit (an even number of rows either way: pairs, 32-row groups)
+        for (uint32_t r0 = 0; r0 < rows_total; r0 += rows_per_grid) {
+            uint32_t rows = std::min<uint32_t>(rows_per_grid, rows_total - r0);
             unsigned char *p8 = d8 ? d8 + (size_t)r0 * w * 3 : nullptr;
             double *p64 = d64 ? d64 + (size_t)r0 * w * 3 : nullptr;
             const double *yv = d_yvals + (size_t)r0 * n_yvals;
@@ -250,8 +259,9 @@ struct JitBackend final : Backend {
             unsigned ww = w, yy0 = y0, tile_base = r0 * n_tx, row_base = r0;
             const unsigned long long *gb = d_gbits;              // indexed by the row of the whole call
             unsigned ntx = n_tx;
-            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles, &blk_rows, &blk_stride, &row_base, &yrows, &row_order};
-            HIP_TRY(hipModuleLaunchKernel(f_pix, gx, rows, 1, 256, 1, 1, 0, st, args, nullptr));
+            unsigned rpw_ = rpw;
+            void *args[] = {&p8, &p64, &yv, &d_tex, &fl, &tile_base, &gb, &ntx, &ww, &yy0, &n_yvals, &tiles, &blk_rows, &blk_stride, &row_base, &yrows, &row_order, &rows, &rpw_};
+            HIP_TRY(hipModuleLaunchKernel(f_pix, gx, (rows + rpw - 1) / rpw, 1, 256, 1, 1, 0, st, args, nullptr));
         }
         if (has_sin) slow->render_flagged(w, rb, d8, d64, st, d_flags, d_yvals);   // no-op unless a tile was deferred
     }

@@ -130,19 +130,21 @@ void mkdirs(const std::string &d)
         if (i == d.size() || d[i] == '/') (void)mkdir(d.substr(0, i).c_str(), 0777);
 }
 
-const uint32_t CACHE_MAGIC = 0x3363726du;    // "mrc3": 9 header words (guard geometry in the header), checksum over header and code
+const uint32_t CACHE_MAGIC = 0x3463726du;    // "mrc4": 10 header words (guard geometry and the two-row flag in the header), checksum over header and code
+const int CACHE_HDR = 10;
 
-uint64_t cache_sum(const uint32_t hdr[9], const JitCode &c)
+uint64_t cache_sum(const uint32_t hdr[CACHE_HDR], const JitCode &c)
 {
-    return fnv1a(c.rows.data(), c.rows.size(), fnv1a(c.pix.data(), c.pix.size(), fnv1a(hdr, 36, 0xcbf29ce484222325ull)));
+    return fnv1a(c.rows.data(), c.rows.size(), fnv1a(c.pix.data(), c.pix.size(), fnv1a(hdr, 4 * CACHE_HDR, 0xcbf29ce484222325ull)));
 }
 
 // The launch geometry comes from this header (the sources it was generated for are not at hand when a file is read), so a
 // damaged one must read as a miss, not as a division by zero or a table indexed past its end: every field is range-checked
 // and the checksum covers the header too.  guard_w: 64 / 128 / 256 pixels; guard_h: a power of two up to 128 rows (1 = guards
 // per row); waves: the occupancies __launch_bounds__ is given.
-bool cache_header_ok(const uint32_t hdr[9])
+bool cache_header_ok(const uint32_t hdr[CACHE_HDR])
 {
+    if (hdr[9] > 1 || (hdr[9] == 1 && hdr[8] < 2)) return false;          // two rows per wavefront need groups of >= 2 rows
     const uint32_t gw = hdr[7], gh = hdr[8];
     return hdr[0] == CACHE_MAGIC && hdr[1] >= 1 && hdr[1] <= 65535 && hdr[2] <= 65535 && (hdr[3] == 0 || hdr[3] == 2 || hdr[3] == 4 || hdr[3] == 6 || hdr[3] == 8) &&
            hdr[4] > 0 && hdr[4] < (1u << 30) && hdr[5] < (1u << 30) && hdr[6] <= 1024 && (gw == 64 || gw == 128 || gw == 256) &&
@@ -153,11 +155,11 @@ bool cache_read(const std::string &path, JitCode &c)
 {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
-    uint32_t hdr[9];
-    bool ok = fread(hdr, 4, 9, f) == 9 && cache_header_ok(hdr);
+    uint32_t hdr[CACHE_HDR];
+    bool ok = fread(hdr, 4, CACHE_HDR, f) == CACHE_HDR && cache_header_ok(hdr);
     if (ok) {
         c.n_row_chunks = hdr[1]; c.n_gjobs = hdr[2]; c.waves = (int)hdr[3];
-        c.n_gwords = hdr[6]; c.guard_w = hdr[7]; c.guard_h = hdr[8];
+        c.n_gwords = hdr[6]; c.guard_w = hdr[7]; c.guard_h = hdr[8]; c.rows2 = hdr[9] != 0;
         c.pix.resize(hdr[4]); c.rows.resize(hdr[5]);
         ok = fread(c.pix.data(), 1, c.pix.size(), f) == c.pix.size() && fread(c.rows.data(), 1, c.rows.size(), f) == c.rows.size();
         uint64_t sum = 0;
@@ -173,10 +175,10 @@ void cache_write(const std::string &dir, const std::string &path, const JitCode 
     const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
     FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return;                                       // a read-only or missing cache directory is not an error
-    const uint32_t hdr[9] = {CACHE_MAGIC, c.n_row_chunks, c.n_gjobs, (uint32_t)c.waves, (uint32_t)c.pix.size(), (uint32_t)c.rows.size(),
-                             c.n_gwords, c.guard_w, c.guard_h};
+    const uint32_t hdr[CACHE_HDR] = {CACHE_MAGIC, c.n_row_chunks, c.n_gjobs, (uint32_t)c.waves, (uint32_t)c.pix.size(), (uint32_t)c.rows.size(),
+                                     c.n_gwords, c.guard_w, c.guard_h, c.rows2 ? 1u : 0u};
     const uint64_t sum = cache_sum(hdr, c);
-    const bool ok = fwrite(hdr, 4, 9, f) == 9 && fwrite(c.pix.data(), 1, c.pix.size(), f) == c.pix.size() &&
+    const bool ok = fwrite(hdr, 4, CACHE_HDR, f) == CACHE_HDR && fwrite(c.pix.data(), 1, c.pix.size(), f) == c.pix.size() &&
                     fwrite(c.rows.data(), 1, c.rows.size(), f) == c.rows.size() && fwrite(&sum, 8, 1, f) == 1;
     if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());      // rename: readers never see half a file
 }
@@ -423,7 +425,7 @@ std::shared_ptr<const JitCode> build_code(const maray_program &prog, CodeKey &k)
     c->n_row_chunks = k.n_row_chunks; c->n_gjobs = k.n_gjobs;
     if (prog.n_row_ops) {          // (the guard plan is a walk over the ROW tape: once here, not in every context's creation)
         const GuardGeom geom = jit_guard_geom(prog);
-        c->n_gwords = jit_guard_words(prog); c->guard_w = geom.gw; c->guard_h = geom.gh;
+        c->n_gwords = jit_guard_words(prog); c->guard_w = geom.gw; c->guard_h = geom.gh; c->rows2 = jit_rows2(prog);
     }
     if (!path.empty()) cache_write(dir, path, *c);
     return c;

@@ -229,6 +229,10 @@ struct Emitter {
         std::string d;   // name / literal of the double, empty until materialised
         std::string b;   // name / literal of the lane mask (BOOL, NEGBOOL)
         uint32_t d_scope = 0;   // the region (C++ block) the materialised double was declared in; 0 = the kernel's own block
+        bool wide = false;      // two rows per lane (Emitter::pair): the value differs between the rows (a pair, mr_p / mr_pm); else one value serves both
+        // value = x + k (cmp_kind 1) or -(x + k) (2) with k a finite constant: Step of it is the compare x >= -k (x <= -k), without
+        // the addition (jit_emit: case MARAY_OP_STEP)
+        int cmp_kind = 0; std::string cmp_x; double cmp_k = 0.0; bool cmp_wide = false;
         bool cst = false;       // a known constant (a literal of the tape, MR_NONE / MR_ALL as numbers, or arithmetic on such): cval
         double cval = 0.0;
     };
@@ -263,6 +267,12 @@ struct Emitter {
     std::string td = "double", tm = "mr_mask";  // types of a value / a boolean in the generated text ("mr_d" / "mr_m": four pixels per lane)
     std::vector<double> ktab_vals;
     std::unordered_map<uint64_t, uint32_t> ktab_block;
+    // Two rows per lane (device_math.h, mr_p / mr_pm): the NARROW passes of a wavefront that owns the same 64 pixels of two
+    // neighbouring rows.  y values and Y are pairs (yv / yw: row r, yv1 / yw1: row r + 1); an op is a pair when an operand is.
+    bool pair = false;
+    std::vector<uint8_t> is_wide_op;             // out: per op of the last section(), was its value a pair
+    std::vector<uint8_t> wide_hint;              // in: the same from a dry run (types the regions' variables, which are declared ahead of their last op)
+    bool fuse_cmp = true;                       // Step(x + k) as one compare (MARAY_JIT_FUSE_CMP=0: ablation)
     bool texel_once = false;                    // PIXEL: App ops of one image on the same coordinates share one mr_texel (descriptors mr_t<image> in scope)
     std::map<std::string, std::pair<std::string, uint32_t>> texels;      // (image, x, y, width) -> its variable and the block it was declared in
     const RedPlan *rplan = nullptr;             // PIXEL: the guarded OR-reductions of the section being emitted (null: walk the tree as written)
@@ -289,6 +299,8 @@ struct Emitter {
         vals.assign(n, Val());
         texels.clear();
         is_bool_op.assign(n, 0);
+        is_wide_op.assign(n, 0);
+        const std::string tdw = pair ? "mr_p" : td, tmw = pair ? "mr_pm" : tm;      // types of a pair
         std::vector<int> slot(n_slots, -1);
         int acc = -1;
         char name[48];
@@ -317,19 +329,24 @@ struct Emitter {
             }
             case MARAY_K_YVAL:
                 t.d = yv_name + "[" + std::to_string(idx) + "]";
-                if (idx < ybool.size() && ybool[idx]) { t.kind = BOOL; t.b = "mr_ym(yw, " + std::to_string(idx) + "u)"; }
+                if (pair) { t.d = "mr_p(" + t.d + ", " + yv_name + "1[" + std::to_string(idx) + "])"; t.wide = true; }
+                if (idx < ybool.size() && ybool[idx]) {
+                    t.kind = BOOL; t.b = "mr_ym(yw, " + std::to_string(idx) + "u)";
+                    if (pair) t.b = "mr_pm(" + t.b + ", mr_ym(yw1, " + std::to_string(idx) + "u))";
+                }
                 return &t;
             default:
                 if (idx == MARAY_SPEC_ACC) return &vals[acc];
                 static const char *const spec_name[] = {"X", "Y", "", "XMAX", "XMIN", "YMAX", "YMIN"};
                 t.d = spec_name[idx];
+                t.wide = pair && idx == MARAY_SPEC_Y;
                 return &t;
             }
         };
         // the double form of a value, materialising it once if needed
         // leaf: the block of a reduction's leaf (no variable, no else).  mask: the lanes on which what the region computes can
         // matter -- a wave-level region of booleans computes q of n = p AND q (p OR q): where p is 0 (1), n does not depend on q
-        struct Open { uint32_t end; bool as_bool; bool nz; uint32_t id; bool leaf; std::string mask; };
+        struct Open { uint32_t end; bool as_bool; bool nz; uint32_t id; bool leaf; std::string mask; bool mask_wide; };
         std::vector<Open> open;     // SKIPZ / SKIPNZ regions being emitted, innermost last
         uint32_t next_scope = 1;
         auto dbl = [&](Val *v, const char *hint, uint32_t i, int which) -> std::string {
@@ -340,7 +357,7 @@ struct Emitter {
             if (v->b == "MR_NONE") return v->d = v->kind == BOOL ? "0.0" : "(-0.0)";
             if (v->b == "MR_ALL") return v->d = v->kind == BOOL ? "1.0" : "(-1.0)";
             snprintf(name, sizeof name, "%s%u_%c", hint, i, which ? 'b' : 'a');
-            out += "    const " + td + " ";
+            out += "    const " + (v->wide ? tdw : td) + " ";
             out += name;
             out += v->kind == BOOL ? " = mr_pos(" + v->b + ");\n" : " = mr_neg01(" + v->b + ");\n";
             v->d = name;
@@ -364,7 +381,7 @@ struct Emitter {
             if (role == RedPlan::IGNORED_SKIP) continue;            // legal: an evaluator may ignore any SKIP op
             if (role == RedPlan::LEAF_SKIP) {
                 out_saved.swap(out);                                // (out_saved was empty: leaves do not nest)
-                open.push_back(Open{i + aux, true, false, next_scope++, true, std::string()});
+                open.push_back(Open{i + aux, true, false, next_scope++, true, std::string(), false});
                 ktab_block.clear();
                 continue;
             }
@@ -428,24 +445,29 @@ struct Emitter {
                         }
                     cond = "(" + (any.empty() ? std::string("0u") : any) + ") != 0u";
                 } else if (row_guard) {
-                    // a y value is uniform over the block: test its bits on the scalar unit, no ballot, no VALU
+                    // a y value is uniform over the block: test its bits on the scalar unit, no ballot, no VALU (two rows per
+                    // lane: the region is entered when either row needs it)
                     const std::string k = std::to_string(MARAY_REF_INDEX(gref));
-                    cond = nz ? "!(yw[2 * " + k + " + 1] == 0x3ff00000u && yw[2 * " + k + "] == 0u)"
-                              : "((yw[2 * " + k + " + 1] << 1) | yw[2 * " + k + "]) != 0u";
+                    auto test = [&](const std::string &yw_) {
+                        return nz ? "!(" + yw_ + "[2 * " + k + " + 1] == 0x3ff00000u && " + yw_ + "[2 * " + k + "] == 0u)"
+                                  : "((" + yw_ + "[2 * " + k + " + 1] << 1) | " + yw_ + "[2 * " + k + "]) != 0u";
+                    };
+                    cond = pair ? "(" + test("yw") + ") || (" + test("yw1") + ")" : test("yw");
                 } else if (as_bool) cond = nz ? "mr_any(~" + va->b + ")" : "mr_any(" + va->b + ")";      // a scalar compare
                 else cond = (nz ? "mr_any(mr_ne1(" : "mr_any(mr_ne0(") + dbl(va, "m", i, 0) + "))";
                 // several regions may end at one op (a row-level guard around a wave-level one): one variable
                 bool typed_bool = as_bool;
                 bool declared = false;
                 for (const Open &o : open) if (o.end == end && !o.leaf) { declared = true; typed_bool = o.as_bool; }
-                if (!declared) out += typed_bool ? "    " + tm + " b" + std::string(name) + ";\n" : "    " + td + " " + std::string(name) + ";\n";
+                const bool wide_var = pair && (end >= wide_hint.size() || wide_hint[end]);      // (no hint: the typing run, whose text is not used)
+                if (!declared) out += typed_bool ? "    " + (wide_var ? tmw : tm) + " b" + std::string(name) + ";\n" : "    " + (wide_var ? tdw : td) + " " + std::string(name) + ";\n";
                 // A region behind a rectangle guard is entered rarely (chess: 4 of the 15 a pass tests): unlikely, so that the block
                 // placement keeps the skip path as the fall-through and moves the bodies out of line (taken jumps stall on
                 // instruction fetch).  A wave-level region of the PIXEL section sits inside a shape whose guard let the wavefront
                 // in, and is entered nine times in ten (18 of 20 per pass): likely (board crop 82.3 -> 81.6 us).
                 out += "    if (__builtin_expect(" + cond + (pixel && !row_guard ? ", 1)) {\n" : ", 0)) {\n");
                 open.push_back(Open{end, typed_bool, nz, next_scope++, false,
-                                    (!row_guard && as_bool && va->kind == BOOL) ? (nz ? "~" + va->b : va->b) : std::string()});
+                                    (!row_guard && as_bool && va->kind == BOOL) ? (nz ? "~" + va->b : va->b) : std::string(), va->wide});
                 ktab_block.clear();
                 continue;
             }
@@ -469,6 +491,7 @@ struct Emitter {
             std::string e;      // double expression
             std::string be;     // bool expression
             const bool both_bool = va && vb && va->kind == BOOL && vb->kind == BOOL;
+            r.wide = pair && ((va && va->wide) || (vb && vb->wide));
             auto m_and = [](const std::string &a, const std::string &b) -> std::string {
                 if (a == "MR_NONE" || b == "MR_NONE") return "MR_NONE";
                 if (a == "MR_ALL") return b;
@@ -491,7 +514,7 @@ struct Emitter {
             // (1,000 triangles: 2.2 ms of the frame's 2.4).
             auto quiet_arg = [&](const std::string &x) -> std::string {
                 std::string m;
-                for (const Open &o : open) if (!o.mask.empty()) m += (m.empty() ? "" : " & ") + o.mask;
+                for (const Open &o : open) if (!o.mask.empty()) { m += (m.empty() ? "" : " & ") + o.mask; if (pair && o.mask_wide) r.wide = true; }      // (a pair of masks makes a pair of arguments)
                 return m.empty() ? x : "mr_sel0(" + m + ", " + x + ")";
             };
             // Arithmetic on known constants is done here (the lowering folded what it could see; what is left appears when a
@@ -530,12 +553,23 @@ struct Emitter {
             else if (role == RedPlan::INNER || role == RedPlan::ROOT) ;     // an OR of a reduction: below
             else
             switch (op) {
-            case MARAY_OP_MOV: r = *va; break;
+            case MARAY_OP_MOV: { const bool w_ = r.wide; r = *va; r.wide = w_ || va->wide; break; }
             case MARAY_OP_NEG:
                 if (va->kind == BOOL) { r.kind = NEGBOOL; r.b = va->b; }
-                else e = "mr_neg(" + dbl(va, "m", i, 0) + ")";
+                else {
+                    e = "mr_neg(" + dbl(va, "m", i, 0) + ")";
+                    if (va->cmp_kind) { r.cmp_kind = 3 - va->cmp_kind; r.cmp_x = va->cmp_x; r.cmp_k = va->cmp_k; }
+                }
                 break;
-            case MARAY_OP_STEP: be = "mr_ge0(" + dbl(va, "m", i, 0) + ")"; break;
+            case MARAY_OP_STEP:
+                // Step(x + k) with k a finite constant is the compare x >= -k, bit for bit: fl(x + k) >= 0 iff x + k >= 0 in the reals
+                // (rounding is monotone and a sum is never rounded to zero: sums in the subnormal range are exact; an exact zero sum
+                // is +0, and Step(+0) = 1 = [x >= -k]); +-inf and NaN agree on both sides.  Step(-(x + k)) likewise is x <= -k
+                // (a zero sum gives -0, Step(-0) = 1).  The addition drops out of the chain in front of the compare -- a shape's
+                // edge tests are `0 <= u < 1`: Step(u) and Step(u - 1) -- and, where nothing else reads it, altogether.
+                if (fuse_cmp && va->kind == DBL && va->cmp_kind && pixel) be = std::string(va->cmp_kind == 1 ? "mr_gek(" : "mr_lek(") + va->cmp_x + ", " + lit(-va->cmp_k) + ")";
+                else be = "mr_ge0(" + dbl(va, "m", i, 0) + ")";
+                break;
             case MARAY_OP_STEPSIN:
                 if ((aux & MARAY_AUX_SIN_BOUNDED) && sin_k >= 0 && td == "double") be = "mr_stepsin_bounded_mk(" + dbl(va, "m", i, 0) + ", mr_kc + " + std::to_string(sin_k) + ")";
                 else if (aux & MARAY_AUX_SIN_BOUNDED) be = "mr_stepsin_bounded_m(" + dbl(va, "m", i, 0) + ")";
@@ -546,7 +580,13 @@ struct Emitter {
                 // 1.0 + (-(b)) = NOT b
                 if (va->kind == BOOL && va->b == "MR_ALL" && vb->kind == NEGBOOL) be = m_not(vb->b);
                 else if (vb->kind == BOOL && vb->b == "MR_ALL" && va->kind == NEGBOOL) be = m_not(va->b);
-                else e = dbl(va, "m", i, 0) + " + " + dbl(vb, "m", i, 1);
+                else {
+                    e = dbl(va, "m", i, 0) + " + " + dbl(vb, "m", i, 1);
+                    for (int q = 0; q < 2; q++) {
+                        const Val *c = q ? vb : va, *x = q ? va : vb;
+                        if (c->cst && std::isfinite(c->cval) && !x->cst && x->kind == DBL && !x->d.empty()) { r.cmp_kind = 1; r.cmp_x = x->d; r.cmp_k = c->cval; break; }
+                    }
+                }
                 break;
             case MARAY_OP_MUL:
                 if (both_bool) be = m_and(va->b, vb->b);
@@ -573,13 +613,13 @@ struct Emitter {
                 if (!(pixel && texel_once)) { e = "mr_app(tex, " + std::to_string(aux) + "u, " + ax + ", " + ay + ")"; break; }
                 // one texel, three channels: the coordinate work and the address are shared by the App ops of one image on the
                 // same two operands (device_math.h, mr_texel); the texel's variable is reused while its block is open
-                const std::string key = std::to_string(aux / 5u) + "|" + ax + "|" + ay + "|" + td;
+                const std::string key = std::to_string(aux / 5u) + "|" + ax + "|" + ay + "|" + td + (r.wide ? "2" : "");
                 auto it = texels.find(key);
                 bool in_scope = false;
                 if (it != texels.end()) { in_scope = it->second.second == 0; for (const Open &o : open) in_scope |= o.id == it->second.second; }
                 if (!in_scope) {
                     const std::string tn = "mr_tx" + std::to_string(i);
-                    out += "    const " + std::string(td == "mr_d" ? "mr_tx4 " : "mr_tx ") + tn + " = mr_texel(mr_t" + std::to_string(aux / 5u) + ", tex, " + ax + ", " + ay + ");\n";
+                    out += "    const " + std::string(td == "mr_d" ? "mr_tx4 " : r.wide ? "mr_tx2 " : "mr_tx ") + tn + " = mr_texel(mr_t" + std::to_string(aux / 5u) + ", tex, " + ax + ", " + ay + ");\n";
                     it = texels.insert_or_assign(key, std::make_pair(tn, open.empty() ? 0u : open.back().id)).first;
                 }
                 e = "mr_texch(" + it->second.first + ", " + std::to_string(aux % 5u) + "u)";
@@ -598,7 +638,7 @@ struct Emitter {
                     if (m != "MR_NONE") red_free[id].push_back(m);
                 }
                 if (role == RedPlan::INNER) {
-                    r.kind = REDPART;
+                    r.kind = REDPART; r.wide = pair;
                     vals[i] = r;
                     is_bool_op[i] = rbool;
                     acc = (int)i;
@@ -611,8 +651,9 @@ struct Emitter {
                 const RedPlan::Red &red = rp->reds[id];
                 const std::string rid = std::to_string(serial) + "_" + std::to_string(id);
                 const std::string racc = "mr_racc" + rid;
+                r.wide = pair;                  // the accumulator is a pair whatever the leaves are: a shape may show on one row only
                 if (rbool) {
-                    out += "    mr_mask " + racc + " = MR_NONE";
+                    out += "    " + std::string(pair ? "mr_pm " : "mr_mask ") + racc + " = MR_NONE";
                     for (const std::string &m : red_free[id]) out += " | " + m;
                     out += ";\n";
                 } else {
@@ -626,7 +667,7 @@ struct Emitter {
                         snprintf(hex, sizeof hex, "0x%llxull", (unsigned long long)mask);
                         all += std::string(all.empty() ? "" : " && ") + "(" + guard_word(wi) + " & " + hex + ") == " + hex;
                     }
-                    out += "    double " + racc + " = (" + all + ") ? __builtin_nan(\"\") : 0.0;\n";
+                    out += "    " + std::string(pair ? "mr_p " : "double ") + racc + " = (" + all + ") ? __builtin_nan(\"\") : 0.0;\n";
                     for (const std::string &m : red_free[id]) out += "    " + racc + " = mr_max(" + racc + ", " + m + ");\n";
                 }
                 for (uint32_t wi = 0; wi < guard_words; wi++) {
@@ -641,7 +682,7 @@ struct Emitter {
                     const std::string w = std::to_string(wi), next = "mr_rn" + rid + "_" + w;
                     const std::string nz = guard_word_nonzero(wi);
                     if (!nz.empty()) out += "    if (" + nz + ")\n";
-                    out += "    for (mr_mask mr_rm = " + guard_word(wi) + " & " + hex + "; mr_rm != 0ull" + (rbool ? " && " + racc + " != MR_ALL" : std::string()) + "; ) {\n"
+                    out += "    for (mr_mask mr_rm = " + guard_word(wi) + " & " + hex + "; mr_rm != 0ull" + (rbool ? " && !mr_covered(" + racc + ")" : std::string()) + "; ) {\n"
                            "        const unsigned mr_rk = (unsigned)__builtin_ctzll(mr_rm);\n"
                            "        mr_rm &= mr_rm - 1ull;\n"
                            "        asm goto(\"s_getpc_b64 s[20:21]\\n\\ts_add_u32 s20, s20, %0\\n\\ts_addc_u32 s21, s21, 0\\n\\ts_setpc_b64 s[20:21]\"";
@@ -659,9 +700,12 @@ struct Emitter {
                     for (int b = 0; b <= top; b++) {
                         if (leaf_of_bit[b] < 0) continue;
                         std::string yf;              // the leaf's y factors: all must hold on this row
-                        for (uint32_t yk : red.leaf_yfactors[leaf_of_bit[b]]) yf += (yf.empty() ? "" : " & ") + std::string("mr_ym(yw, ") + std::to_string(yk) + "u)";
+                        for (uint32_t yk : red.leaf_yfactors[leaf_of_bit[b]]) {
+                            const std::string k_ = std::to_string(yk);
+                            yf += (yf.empty() ? "" : " & ") + (pair ? "mr_pm(mr_ym(yw, " + k_ + "u), mr_ym(yw1, " + k_ + "u))" : "mr_ym(yw, " + k_ + "u)");
+                        }
                         out += "    mr_rl" + rid + "_" + std::to_string(leaf_of_bit[b]) + ": {\n" +
-                               (yf.empty() ? std::string() : "    if ((" + yf + ") == MR_NONE) goto " + next + ";      // not on this row (frame 29.5 -> 29.0 us)\n") +
+                               (yf.empty() ? std::string() : "    if (!mr_any(" + yf + ")) goto " + next + ";      // not on this row (frame 29.5 -> 29.0 us)\n") +
                                red_leaf_text[id][leaf_of_bit[b]] + "    } goto " + next + ";\n";
                     }
                     out += "    " + next + ": ;\n    }\n";
@@ -675,6 +719,7 @@ struct Emitter {
                 // the AND / OR that ends a region: assign the variable declared before the `if`
                 const Open o = open.back();
                 open.pop_back();
+                if (pair && i < wide_hint.size()) r.wide = wide_hint[i] != 0;      // (= the width its variable was declared with; the typing run has no hint and finds it)
                 if (o.as_bool && !be.empty()) {
                     out += "    b" + self + " = " + be + ";\n    } else b" + self + (o.nz ? " = MR_ALL;\n" : " = MR_NONE;\n");
                     r.kind = BOOL; r.b = "b" + self;
@@ -694,16 +739,16 @@ struct Emitter {
                                      : "    } else " + self + (o2.nz ? " = 1.0;\n" : " = 0.0;\n");
                 }
             } else if (be == "MR_NONE" || be == "MR_ALL") {
-                r.kind = BOOL; r.b = be;             // a literal: later ops fold it
+                r.kind = BOOL; r.b = be; r.wide = false;      // a literal: later ops fold it
             } else if (!be.empty() && be[0] != '(' && be[0] != '~' && be.compare(0, 3, "mr_") != 0) {
                 r.kind = BOOL; r.b = be;             // folded to one of its operands: an alias, no new variable
             } else if (!be.empty()) {
-                out += "    const " + tm + " b" + self + " = " + be + ";\n";
+                out += "    const " + (r.wide ? tmw : tm) + " b" + self + " = " + be + ";\n";
                 r.kind = BOOL; r.b = "b" + self;
             } else if (!e.empty() && folded) {
-                r.kind = DBL; r.d = e; r.cst = true; r.cval = fold_val;      // a literal: no statement
+                r.kind = DBL; r.d = e; r.cst = true; r.cval = fold_val; r.wide = false;      // a literal: no statement
             } else if (!e.empty()) {
-                out += "    const " + td + " " + self + " = " + e + ";\n";
+                out += "    const " + (r.wide ? tdw : td) + " " + self + " = " + e + ";\n";
                 r.kind = DBL; r.d = self;
             }
             if (role == RedPlan::LEAF_END) {
@@ -719,8 +764,9 @@ struct Emitter {
                 out_saved.clear();
                 ktab_block.clear();
                 r = Val();
-                r.kind = REDPART;
+                r.kind = REDPART; r.wide = pair;
                 vals[i] = r;
+                is_wide_op[i] = pair;
                 is_bool_op[i] = 1;
                 acc = (int)i;
                 if (dst != MARAY_DST_NONE) slot[dst] = (int)i;
@@ -728,6 +774,7 @@ struct Emitter {
             }
             vals[i] = r;
             is_bool_op[i] = r.kind == BOOL;
+            is_wide_op[i] = r.wide;
             acc = (int)i;
             if (dst != MARAY_DST_NONE) slot[dst] = (int)i;
         }

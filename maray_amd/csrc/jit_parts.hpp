@@ -27,5 +27,6 @@ bool may_defer_tiles(const maray_program &P);                       // some Sin 
 uint32_t jit_guard_words(const maray_program &P);                   // 64-bit words of guard bits per rectangle
 GuardGeom jit_guard_geom(const maray_program &P);
 bool jit_wide_general(const maray_program &P, uint32_t n_gwords);   // the general section four pixels per lane
+bool jit_rows2(const maray_program &P);                             // busy tiles two rows per wavefront (the launch passes rpw = 2 when its guard groups allow)
 
 }   // namespace maray

@@ -339,6 +339,18 @@ bool jit_wide_general(const maray_program &P, uint32_t n_gwords)        // n_gwo
     return n_gwords == 0 && !heavy && P.n_pix_slots <= 6 && P.n_pix_ops <= 256;
 }
 
+// Two rows per wavefront in the busy tiles (jit_source): a program whose shapes are guarded per rectangle of an even number
+// of rows, evaluated one pixel per lane.  MARAY_JIT_ROWS2=0 / 1: off / on (ablation; part of the code key like every MARAY_JIT_*).
+bool jit_rows2(const maray_program &P)
+{
+    const char *e_ = getenv("MARAY_JIT_ROWS2");
+    if (!(e_ && e_[0] == '1')) return false;
+    const uint32_t nw = jit_guard_words(P);
+    if (!nw || nw > GW_INLINE_MAX || jit_wide_general(P, nw)) return false;
+    const GuardGeom g = jit_guard_geom(P);
+    return g.gh >= 2 && g.gh % 2 == 0;
+}
+
 // Source of the PIXEL kernel, maray_jit_pixels.  A wavefront owns a strip of `tiles` consecutive 256-pixel tiles of one
 // row (blockIdx.y); a block is four wavefronts = four neighbouring strips that share nothing but the instruction cache:
 // no staging, no barrier.  The strip's guard words arrive with one vector load (lane i = word i); per tile one scalar
@@ -377,6 +389,7 @@ std::string jit_source(const maray_program &P, int min_waves)
     E.min_region = 12;
     if (const char *e_ = getenv("MARAY_JIT_MIN_REGION")) E.min_region = (uint32_t)atoi(e_);
     E.ybool = jit_bool_yvals(P);
+    if (const char *e_ = getenv("MARAY_JIT_FUSE_CMP")) E.fuse_cmp = e_[0] != '0';
     E.ktab = true;
     for (uint32_t i = 0; i < P.n_pix_ops && E.sin_k < 0; i++)
         if (MARAY_INS_OP(P.pix_ops[i]) == MARAY_OP_STEPSIN) {
@@ -410,18 +423,24 @@ std::string jit_source(const maray_program &P, int min_waves)
     // compiler gets 80 and spilled ~400 of them to VGPR lanes, in the skeleton every pass walked); with the tree evaluated as
     // a reduction chess fits 78 and runs 8 (frame 29.9 -> 29.5 us, sky 12.3 -> 11.5, board 67.1 -> 65.1)
     if (min_waves_arg == 0) min_waves = reductions.empty() ? 6 : 8;
+    // two rows per wavefront: twice the lane masks alive (chess at 8 waves: 240 SGPRs spilled to VGPR lanes); MARAY_JIT_ROWS2_WAVES: ablation
+    if (min_waves_arg == 0 && jit_rows2(P)) { min_waves = 6; if (const char *e_ = getenv("MARAY_JIT_ROWS2_WAVES")) if (atoi(e_) > 0) min_waves = atoi(e_); }
     const bool defer = may_defer_tiles(P);
     const std::string nw = std::to_string(n_gwords);
     // a strip's guard words: one vector load per wavefront (lane i holds word i), then v_readlane per tile or pass -- one
     // memory latency per strip instead of one per tile
     const bool gw_vgpr = n_gwords && n_gwords <= GW_INLINE_MAX;
     const bool wide_general = jit_wide_general(P, n_gwords);
+    // Two rows per wavefront (jit_rows2): the busy tiles' passes take the same 64 pixels of two neighbouring rows of one guard
+    // rectangle -- the same shapes are entered for both, so a shape's dispatch, its constants and its x-only arithmetic are
+    // paid once per 128 pixels (device_math.h, mr_p).  Needs guards bounded over rectangles of an even number of rows.
+    const bool pair = jit_rows2(P);
     const std::string esub = "(e >> " + std::to_string(sub == 4 ? 0 : 1) + "u)";       // rectangle of pass e inside its tile
     s += "// generated by libmaray_hip (jit_source.cpp) from a v" + std::to_string(P.version) + " tape: PIXEL section, " +
          std::to_string(P.n_pix_ops) + " ops; general variant " + (wide_general ? "four pixels per lane" : "one pixel per lane, four passes per tile") + "\n"
          "#define MR_VEC4 1\n"
          "__shared__ unsigned mr_slow[4];           // per wavefront: some Sin of the tile at hand needs the slow path\n"
-         "__shared__ unsigned mr_tp[4 * 256];       // per wavefront: the packed pixels of a tile's four passes\n"
+         "__shared__ unsigned mr_tp[4 * " + std::string(pair ? "512" : "256") + "];       // per wavefront: the packed pixels of a tile's four passes (of both rows)\n"
          "__device__ inline double mr_defer_sin(double) { ((volatile unsigned *)mr_slow)[threadIdx.x >> 6] = 1u; return 0.0; }\n"
          "#define MR_SIN_HUGE(x) mr_defer_sin(x)   // plain Sin ops: flag the tile from the (rare) branch\n"
          "#include \"device_math.h\"\n"
@@ -440,17 +459,29 @@ std::string jit_source(const maray_program &P, int min_waves)
          "                                                                    const unsigned long long *__restrict__ gbits, unsigned n_tx,\n"
          "                                                                    unsigned w, unsigned y0, unsigned n_yvals, unsigned tiles,\n"
          "                                                                    unsigned blk_rows, unsigned blk_stride, unsigned row_base, unsigned yrows,\n"
-         "                                                                    const unsigned *__restrict__ row_order)\n{\n"
+         "                                                                    const unsigned *__restrict__ row_order, unsigned rows, unsigned rpw)\n{\n"
          "    const unsigned mr_wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), mr_lane = threadIdx.x & 63u;\n"
          "    // (workgroups go to the 8 XCDs round robin by their linear id: with 2, 4 or 8 blocks per row a column of the image\n"
          "    // always meets the same XCDs; rotating a row's strips by the row was measured and is not worth it, DESIGN.md 7.1)\n"
          "    const unsigned tile0 = (blockIdx.x * 4u + mr_wv) * tiles;               // this wavefront's strip of the row\n"
          "    if (tile0 >= n_tx) return;\n"
-         "    const unsigned r = row_order ? row_order[blockIdx.y] : blockIdx.y;     // row of this launch (dearest groups of rows first); row_base + r = row of the whole call\n"
+         "    // rows of this launch (dearest groups of rows first); row_base + r = row of the whole call.  rpw = 2 (two-row kernels, when the\n"
+         "    // launch's guard groups have an even number of rows): this wavefront owns rows r and r + 1 of one group\n"
+         "    const unsigned mr_rr = blockIdx.y * rpw;\n"
+         "    const unsigned r = row_order ? row_order[mr_rr] : mr_rr;\n"
+         "    (void)rows;\n" +
+         (pair ? std::string(
+         "    const bool mr_has1 = rpw == 2u && mr_rr + 1u < rows;                  // (else the second row of the pair repeats the first and is not stored)\n"
+         "    const unsigned r1 = mr_has1 ? r + 1u : r;\n"
+         "    const unsigned long long mr_ybase0 = (unsigned long long)(yvals + (size_t)r * n_yvals), mr_ybase1 = (unsigned long long)(yvals + (size_t)r1 * n_yvals);\n"
+         "    const double Y0 = (double)(blk_stride == 0u ? y0 + row_base + r : y0 + ((row_base + r) / blk_rows) * blk_stride + (row_base + r) % blk_rows);\n"
+         "    const double Y1 = (double)(blk_stride == 0u ? y0 + row_base + r1 : y0 + ((row_base + r1) / blk_rows) * blk_stride + (row_base + r1) % blk_rows);\n"
+         "    (void)Y0; (void)Y1; (void)tex; (void)gbits; (void)yrows; (void)tile_list; (void)tile_base;\n")
+               : std::string(
          "    const unsigned long long mr_ybase0 = (unsigned long long)(yvals + (size_t)r * n_yvals);\n"
          "    // -> image row (RowBlocks); one range of rows (blk_stride == 0) needs no division, and yrows is a power of two\n"
          "    const double Y = (double)(blk_stride == 0u ? y0 + row_base + r : y0 + ((row_base + r) / blk_rows) * blk_stride + (row_base + r) % blk_rows);\n"
-         "    (void)Y; (void)tex; (void)gbits; (void)yrows; (void)tile_list; (void)tile_base;\n";
+         "    (void)Y; (void)tex; (void)gbits; (void)yrows; (void)tile_list; (void)tile_base;\n"));
     {   // the descriptors of the textures the section samples: scalar loads, once per wavefront
         std::vector<uint8_t> used;
         for (uint32_t i = 0; i < P.n_pix_ops; i++)
@@ -470,7 +501,7 @@ std::string jit_source(const maray_program &P, int min_waves)
     s += "    const bool mr_wide = rgb64 == nullptr;                                   // wide variants: element e of lane l is pixel x0 + 4 l + e, else x0 + 64 e + l\n"
          "    const unsigned mr_xl = mr_wide ? 4u * mr_lane : mr_lane, mr_xs = mr_wide ? 1u : 64u;\n"
          "    const unsigned mr_src = (mr_lane * 4u) / 3u, mr_shift = ((mr_lane * 4u) % 3u) * 8u;   // RGB8 packing of one 64-pixel run\n"
-         "    const size_t row_px = (size_t)r * w;\n"
+         + std::string(pair ? "    const size_t row_px0 = (size_t)r * w, row_px1 = (size_t)r1 * w;\n" : "    const size_t row_px = (size_t)r * w;\n") +
          "    for (unsigned t = 0; t < tiles; t++) {\n"
          "    const unsigned x0 = (tile0 + t) * 256u;\n"
          "    if (x0 >= w) break;\n"
@@ -492,12 +523,20 @@ std::string jit_source(const maray_program &P, int min_waves)
     if (defer) s += "    ((volatile unsigned *)mr_slow)[mr_wv] = 0u;\n    bool mr_slow_tile = false;\n";
     // what opens a pass of either width: the tables made opaque (LICM would hoist every constant and y value out of the
     // loops and spill them), the pixel coordinates, the outputs
-    const std::string opaque =
-        "    unsigned long long mr_ybase = mr_ybase0;\n"
+    const std::string opaque = std::string(
+        pair ? "    unsigned long long mr_ybase = mr_q ? mr_ybase1 : mr_ybase0;      // (wide tiles of a two-row kernel: row after row)\n"
+             : "    unsigned long long mr_ybase = mr_ybase0;\n") +
         "    asm volatile(\"\" : \"+s\"(mr_ybase));\n"
         "    mr_kptr yv = (mr_kptr)mr_ybase;\n"
         "    const __attribute__((address_space(4))) unsigned *yw = (const __attribute__((address_space(4))) unsigned *)yv;\n"
         "    (void)yv; (void)yw;\n/*MR_KC*/";
+    // the tables of both rows of a pair
+    const std::string opaque2 =
+        "    unsigned long long mr_ybase = mr_ybase0, mr_ybaseb = mr_ybase1;\n"
+        "    asm volatile(\"\" : \"+s\"(mr_ybase), \"+s\"(mr_ybaseb));\n"
+        "    mr_kptr yv = (mr_kptr)mr_ybase, yv1 = (mr_kptr)mr_ybaseb;\n"
+        "    const __attribute__((address_space(4))) unsigned *yw = (const __attribute__((address_space(4))) unsigned *)yv, *yw1 = (const __attribute__((address_space(4))) unsigned *)yv1;\n"
+        "    (void)yv; (void)yw; (void)yv1; (void)yw1;\n/*MR_KC*/";
     // the guard words of the rectangle at hand, opaque anew in every pass: left visible, all their bit tests are loop
     // invariants too (168 booleans for chess, hoisted and spilled to VGPR lanes)
     std::string gq_pass;
@@ -523,7 +562,11 @@ std::string jit_source(const maray_program &P, int min_waves)
                        "    (void)mr_gnz" + k + ";\n";
         }
     const std::string wide_open =
-        "    {\n" + opaque + (sub > 1 ? std::string() : gq_pass) +
+        std::string(pair ? "    for (unsigned mr_q = 0; mr_q <= (unsigned)mr_has1; mr_q++) {\n"
+                           "    const double Y = mr_q ? Y1 : Y0;\n"
+                           "    const size_t row_px = mr_q ? row_px1 : row_px0;\n"
+                           "    (void)Y;\n"
+                         : "    {\n") + opaque + (sub > 1 ? std::string() : gq_pass) +
         "    const unsigned xa = x0 + mr_xl;                                        // this lane's first pixel\n"
         "    const mr_d X((double)xa, (double)(xa + mr_xs), (double)(xa + 2u * mr_xs), (double)(xa + 3u * mr_xs));\n"
         "    mr_d o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"
@@ -578,7 +621,8 @@ std::string jit_source(const maray_program &P, int min_waves)
         "}\n";
     std::string tile_end;         // closes a tile: the work list entry of a tile some Sin of which needs the slow path
     if (defer)
-        tile_end = "    if (mr_slow_tile && mr_lane == 0u) tile_list[1u + atomicAdd(&tile_list[0], 1u)] = tile_base + r * n_tx + tile0 + t;\n";
+        tile_end = "    if (mr_slow_tile && mr_lane == 0u) tile_list[1u + atomicAdd(&tile_list[0], 1u)] = tile_base + r * n_tx + tile0 + t;\n" +
+                   std::string(pair ? "    if (mr_slow_tile && mr_has1 && mr_lane == 0u) tile_list[1u + atomicAdd(&tile_list[0], 1u)] = tile_base + r1 * n_tx + tile0 + t;\n" : "");
 
     if (n_gwords) {
         // the variant of a tile with no guard bit set, four pixels per lane
@@ -608,6 +652,53 @@ std::string jit_source(const maray_program &P, int min_waves)
         s += wide_open;
         E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
         s += wide_close + tile_end;
+    } else if (pair) {
+        // one wavefront, four passes of 64 pixels x 2 rows: a value that depends on the row is a pair (mr_p), the rest is
+        // computed once; the packed pixels of both rows go to LDS and each row's tile is stored as a dwordx3 per lane
+        E.td = "double"; E.tm = "mr_mask";
+        E.pair = true;
+        E.rplan = &reductions;
+        {   // typing run: which ops yield pairs (the regions' variables are declared ahead of their last op)
+            Emitter T(E);
+            T.wide_hint.clear();
+            T.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+            E.wide_hint = T.is_wide_op;
+        }
+        s += "    const bool mr_al0 = x0 + 256u <= w && ((size_t)(rgb8 + (row_px0 + x0) * 3) & 3u) == 0u, mr_al1 = x0 + 256u <= w && ((size_t)(rgb8 + (row_px1 + x0) * 3) & 3u) == 0u;\n"
+             "    const bool mr_fast = rgb8 && mr_al0 && mr_al1;      // wave-uniform\n"
+             "    _Pragma(\"unroll 1\") for (unsigned e = 0; e < 4u; e++) {\n" + opaque2 + gq_pass +
+             "    const unsigned xw = x0 + 64u * e, x = xw + mr_lane;\n"
+             "    const double X = (double)x;\n"
+             "    const mr_p Y(Y0, Y1);\n"
+             "    mr_p o0 = 0.0, o1 = 0.0, o2 = 0.0;\n"
+             "    float mr_defer = 0.0f;\n"
+             "    (void)X; (void)Y; (void)mr_defer;\n";
+        E.section(P.pix_ops, P.n_pix_ops, P.n_pix_slots, true, "v");
+        E.rplan = nullptr;
+        E.pair = false;
+        s += defer_pass +
+             "    const unsigned pk0 = mr_cast_u8(o0.a) | (mr_cast_u8(o1.a) << 8) | (mr_cast_u8(o2.a) << 16);\n"
+             "    const unsigned pk1 = mr_cast_u8(o0.b) | (mr_cast_u8(o1.b) << 8) | (mr_cast_u8(o2.b) << 16);\n"
+             "    if (mr_fast) {\n"
+             "        mr_tp[mr_wv * 512u + 64u * e + mr_lane] = pk0;\n"
+             "        mr_tp[mr_wv * 512u + 256u + 64u * e + mr_lane] = pk1;\n"
+             "        mr_store_run(nullptr, rgb64, row_px0, xw, w, mr_lane, mr_src, mr_shift, pk0, o0.a, o1.a, o2.a);\n"
+             "        if (mr_has1) mr_store_run(nullptr, rgb64, row_px1, xw, w, mr_lane, mr_src, mr_shift, pk1, o0.b, o1.b, o2.b);\n"
+             "    } else {\n"
+             "        mr_store_run(rgb8, rgb64, row_px0, xw, w, mr_lane, mr_src, mr_shift, pk0, o0.a, o1.a, o2.a);\n"
+             "        if (mr_has1) mr_store_run(rgb8, rgb64, row_px1, xw, w, mr_lane, mr_src, mr_shift, pk1, o0.b, o1.b, o2.b);\n"
+             "    }\n"
+             "    }\n"
+             "    if (mr_fast) {\n"
+             "        __builtin_amdgcn_wave_barrier();                                     // same wavefront wrote them: LDS keeps its order\n"
+             "        for (unsigned mr_q = 0; mr_q <= (unsigned)mr_has1; mr_q++) {\n"
+             "            const mr_u4 p = *(const mr_u4 *)&mr_tp[mr_wv * 512u + 256u * mr_q + 4u * mr_lane];\n"
+             "            mr_u3 d;\n"
+             "            d.a = p.a | (p.b << 24); d.b = (p.b >> 8) | (p.c << 16); d.c = (p.c >> 16) | (p.d << 8);\n"
+             "            *(mr_u3 *)(rgb8 + ((mr_q ? row_px1 : row_px0) + x0 + 4u * mr_lane) * 3) = d;\n"
+             "        }\n"
+             "        __builtin_amdgcn_wave_barrier();\n"
+             "    }\n" + tile_end;
     } else {
         // one wavefront, four passes of 64 pixels (a loop, not unrolled); the passes leave their packed pixels in LDS
         // (same-wave traffic: no barrier) and a whole aligned tile is stored as a dwordx3 per lane

@@ -615,6 +615,49 @@ def test_corner_cases():
     ctx.close()
 
 
+def test_step_of_a_sum_with_a_constant_is_one_compare():
+    """The specialised kernels evaluate Step(v + k), k a constant, as the compare v >= -k (and Step(-(v + k)) as v <= -k) without
+    the addition (jit_emit.hpp).  Exact only because a floating-point sum is never rounded to zero and an exact zero sum is +0:
+    here v runs through the values next to -k on both sides (one ulp, a subnormal's distance), through +0 and -0, huge values
+    that absorb k, +-inf and NaN, for k = 0, 1, -1, tiny, huge and 2^-1074 -- all three back-ends against the oracle, f64 planes
+    and bytes.  /root/reference/src/lib.rs:644-647 (Step), :651 (Add)."""
+    # v(x): a table of interesting values selected by x through steps: v = sum_i t_i * [x == i]
+    import struct
+
+    def f64(bits):
+        return struct.unpack('<d', struct.pack('<Q', bits))[0]
+    bools, sums = [], []
+    for k_num, k_den in ((0, 1), (1, 1), (3, 1), (1, 3), (1, 1 << 60), (1 << 62, 1)):
+        for sign in (1, -1):
+            k = div(nat(k_num), nat(k_den))
+            if sign < 0:
+                k = neg(k)
+            # v = (x - 8) * 2^-e: exact multiples crossing zero; that minus k (crossing -k); that over (y - 1): +-inf and NaN on row 1
+            for e in (0, 30, 990):
+                sc = nat(1)
+                for _ in range(e // 30):
+                    sc = mul(sc, recip(nat(1 << 30)))
+                u = mul(sub(x(), nat(8)), sc)
+                for v in (u, sub(u, k), mul(u, recip(sub(y(), nat(1)))), sub(recip(sub(x(), nat(8))), recip(sub(x(), nat(8))))):
+                    bools.append(step(add(v, k)))
+                    bools.append(step(neg(add(k, v))))
+                if e == 30:
+                    sums.append(mul(step(add(u, k)), add(u, k)))      # the sum read by something else as well
+    # 24 booleans a channel, as the bits of an exactly representable sum
+    chans = []
+    for i in range(0, len(bools), 24):
+        acc = nat(0)
+        for j, b_ in enumerate(bools[i:i + 24]):
+            acc = add(acc, mul(b_, nat(1 << j)))
+        chans.append(acc)
+    chans += sums
+    while len(chans) % 3:
+        chans.append(nat(0))
+    w, h = 17, 3
+    for i in range(0, len(chans), 3):
+        gpu_vs_oracle(encode((w, h), chans[i:i + 3]), w, h, [(0, h)])
+
+
 def test_sqrt_of_tiny_zero_negative_and_infinite_arguments():
     """Sqrt scales arguments below 2^-767 (the Newton steps would lose bits); the device asks once per wavefront whether
     any lane needs that (device_math.h, mr_sqrt).  Subnormals, values either side of the threshold, zeros of both signs,
@@ -820,7 +863,8 @@ def test_specialised_kernel_variants_selected_by_tuning_knobs(chess_bytes, monke
     for env in ({'MARAY_JIT_TILES': '1'}, {'MARAY_JIT_TILES': '5'}, {'MARAY_JIT_GUARD_W': '256', 'MARAY_JIT_GUARD_H': '8'},
                 {'MARAY_JIT_GUARD_W': '128', 'MARAY_JIT_GUARD_H': '16', 'MARAY_JIT_TILES': '3'}, {'MARAY_JIT_GUARD_W': '64', 'MARAY_JIT_GUARD_H': '128'},
                 {'MARAY_JIT_MIN_REGION': '0'}, {'MARAY_JIT_MIN_REGION': '100000'}, {'MARAY_JIT_ROW_GUARDS': '0'},
-                {'MARAY_JIT_HELPER': '0', 'MARAY_JIT_OPT': '-O1'}):
+                {'MARAY_JIT_HELPER': '0', 'MARAY_JIT_OPT': '-O1'}, {'MARAY_JIT_ROWS2': '1'}, {'MARAY_JIT_ROWS2': '1', 'MARAY_JIT_TILES': '3'},
+                {'MARAY_JIT_ROWS2': '0'}, {'MARAY_JIT_TEXEL_ONCE': '0'}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         ctx = M.Context(tape, backend=M.BACKEND_JIT)

@@ -227,20 +227,20 @@ def test_a_damaged_cache_file_is_a_miss(tmp_path):
     n0 = run()
     (path,) = glob.glob(str(tmp_path / '*.mrco'))
     good = open(path, 'rb').read()
-    hdr = list(struct.unpack('<9I', good[:36]))
-    assert hdr[0] == 0x3363726d and hdr[4] == n0 and hdr[7] in (64, 128, 256) and len(good) == 36 + hdr[4] + hdr[5] + 8
+    hdr = list(struct.unpack('<10I', good[:40]))
+    assert hdr[0] == 0x3463726d and hdr[4] == n0 and hdr[7] in (64, 128, 256) and hdr[9] in (0, 1) and len(good) == 40 + hdr[4] + hdr[5] + 8
 
     def fnv(data, h=0xcbf29ce484222325):
         for b in data:
             h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
         return h
-    assert struct.unpack('<Q', good[-8:])[0] == fnv(good[36 + hdr[4]:-8], fnv(good[36:36 + hdr[4]], fnv(good[:36])))     # the sum covers the header
-    for field, value in ((7, 0), (7, 96), (8, 24), (8, 0), (6, 5000), (3, 3), (1, 0)):
+    assert struct.unpack('<Q', good[-8:])[0] == fnv(good[40 + hdr[4]:-8], fnv(good[40:40 + hdr[4]], fnv(good[:40])))     # the sum covers the header
+    for field, value in ((7, 0), (7, 96), (8, 24), (8, 0), (6, 5000), (3, 3), (1, 0), (9, 2)):
         bad = list(hdr)
         bad[field] = value
-        head = struct.pack('<9I', *bad)
-        body = good[36:-8]
-        forged = head + body + struct.pack('<Q', fnv(good[36 + hdr[4]:-8], fnv(good[36:36 + hdr[4]], fnv(head))))   # checksum made to fit
+        head = struct.pack('<10I', *bad)
+        body = good[40:-8]
+        forged = head + body + struct.pack('<Q', fnv(good[40 + hdr[4]:-8], fnv(good[40:40 + hdr[4]], fnv(head))))   # checksum made to fit
         for blob in (forged, head + body + good[-8:]):
             open(path, 'wb').write(blob)
             os.utime(path, (1, 1))
