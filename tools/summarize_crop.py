@@ -9,7 +9,7 @@ import sys
 
 d = sys.argv[1]
 run = json.loads([l for l in open(d + '/run.json') if l.startswith('{')][-1])
-out = {'run': run, 'kernels': {}}
+out = {'run': run, 'code_key': run.get('code_key'), 'library': run.get('library'), 'commit': None, 'kernels': {}}      # commit: stamped by tools/collect_r4.py (the GPU box has no .git)
 stats = glob.glob(d + '/trace/*/*_kernel_stats.csv')
 if stats:
     out['kernel_stats'] = [r for r in csv.DictReader(open(stats[0])) if 'maray' in r['Name']]
@@ -45,6 +45,10 @@ for k, c in per.items():
             dv['salu_insts_per_cycle_per_cu'] = avg['SQ_INSTS_SALU'] / 256 / cyc
     if 'SQ_ACTIVE_INST_VALU' in avg and 'SQ_BUSY_CYCLES' in avg:
         dv['SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES'] = avg['SQ_ACTIVE_INST_VALU'] / avg['SQ_BUSY_CYCLES']
+    if 'TCP_TOTAL_CACHE_ACCESSES_sum' in avg and 'TCP_TCC_READ_REQ_sum' in avg and avg['TCP_TOTAL_CACHE_ACCESSES_sum']:
+        dv['tcp_hit_rate (1 - TCP_TCC_READ_REQ / TCP_TOTAL_CACHE_ACCESSES)'] = 1 - avg['TCP_TCC_READ_REQ_sum'] / avg['TCP_TOTAL_CACHE_ACCESSES_sum']
+    if 'TCC_HIT_sum' in avg and avg.get('TCC_HIT_sum', 0) + avg.get('TCC_MISS_sum', 0):
+        dv['l2_hit_rate'] = avg['TCC_HIT_sum'] / (avg['TCC_HIT_sum'] + avg['TCC_MISS_sum'])
     if 'FETCH_SIZE' in avg:
         dv['hbm_fetch_bytes_x2_gfx950_correction'] = avg['FETCH_SIZE'] * 2048
     if 'WRITE_SIZE' in avg:
