@@ -78,43 +78,10 @@ def test_png_reader_with_crafted_headers_under_asan_ubsan(tmp_path):
         'not_png.png': b'P6 5 7 255 ' + raw,
     }
     paths = []
-    # Headers that lie about sizes no file of a few hundred bytes can hold (ADVICE round 3): nothing may be allocated,
-    # reserved or zero-filled on a header's word.  These are also run by an unsanitized build under a 1 GiB address-space
-    # limit below: an allocation the size of the lie would fail there (or, unlimited, zero-fill gigabytes).
-    def tif(w, h, comp, spp, bits, data):
-        ents = [(256, 4, 1, w), (257, 4, 1, h), (258, 3, 1, bits), (259, 3, 1, comp), (262, 3, 1, 2 if spp >= 3 else 1), (273, 4, 1, 8 + 2 + 12 * 10 + 4),
-                (277, 3, 1, spp), (278, 4, 1, h), (279, 4, 1, len(data)), (284, 3, 1, 1)]
-        ifd = struct.pack('<H', len(ents)) + b''.join(struct.pack('<HHII', t, ty, n, v) for t, ty, n, v in ents) + struct.pack('<I', 0)
-        return b'II*\0' + struct.pack('<I', 8) + ifd + data
-    gif_1x1 = b'\x2C' + struct.pack('<HHHHB', 0, 0, 1, 1, 0x80) + bytes(6) + bytes([2, 2, 0x4C, 0x01, 0]) + b'\x3B'
-    lies = {
-        'gif_blank_screen.gif': b'GIF89a' + struct.pack('<HHBBB', 0xFFFF, 0xFFFF, 0, 0, 0) + gif_1x1,            # 40 bytes, 12.9 GB of screen
-        'gif_blank_screen2.gif': b'GIF89a' + struct.pack('<HHBBB', 20000, 20000, 0, 0, 0) + gif_1x1,
-        'gif_frame_lies.gif': b'GIF89a' + struct.pack('<HHBBB', 9000, 9000, 0, 0, 0) + b'\x2C' + struct.pack('<HHHHB', 0, 0, 9000, 9000, 0x80) + bytes(6) + bytes([2, 2, 0x4C, 0x01, 0]) + b'\x3B',
-        'tif_zip_lies.tif': tif(60000, 60000, 8, 8, 16, bytes(40)), 'tif_lzw_lies.tif': tif(60000, 60000, 5, 8, 16, bytes(40)),
-        'tif_pb_lies.tif': tif(60000, 60000, 32773, 3, 8, bytes(40)), 'tif_raw_lies.tif': tif(60000, 60000, 1, 3, 8, bytes(40)),
-        'tga_rle_lies.tga': bytes([0, 0, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0xFF, 0xFF, 0xFF, 0xFF, 32, 0, 0xFF, 1, 2, 3, 4]),
-        'tga_raw_lies.tga': bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0xFF, 0xFF, 0xFF, 0xFF, 32, 0]) + bytes(64),
-        'qoi_lies.qoi': b'qoif' + struct.pack('>IIBB', 40000, 40000, 3, 0) + bytes([0xFD] * 20) + bytes(8),
-        'ff_lies.ff': b'farbfeld' + struct.pack('>II', 40000, 40000) + bytes(64),
-        'bmp_lies.bmp': bmp(40000, 40000, 24, body=bytes(100)), 'pnm_lies.ppm': b'P6 40000 40000 255\n' + bytes(100), 'pnm_lies.pbm': b'P4 60000 60000\n' + bytes(100),
-        'pnm_lies_plain.pgm': b'P2 40000 40000 255\n1 2 3',
-    }
-    files.update(lies)
     for name, data in files.items():
         p = str(tmp_path / name)
         open(p, 'wb').write(data)
         paths.append(p)
-    plain = str(tmp_path / 'image_plain')
-    subprocess.check_call(['g++', '-std=c++17', '-O1', '-I' + csrc, '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'native', 'image_asan.cpp'),
-                           os.path.join(csrc, 'png.cpp'), os.path.join(csrc, 'image.cpp'), '-o', plain, '-lz'])
-    import resource
-
-    def limit():
-        resource.setrlimit(resource.RLIMIT_AS, (1 << 30, 1 << 30))
-    out = subprocess.run([plain] + [str(tmp_path / n) for n in lies] + [paths[0]], capture_output=True, text=True, preexec_fn=limit)
-    assert out.returncode == 0 and 'images ok' in out.stdout and 'out of memory' not in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
-    assert out.stdout.count('rc 0') == 1                                    # only the good file decodes
     env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=1:allocator_may_return_null=1:max_allocation_size_mb=4096',
                UBSAN_OPTIONS='print_stacktrace=1')
     out = subprocess.run([exe] + paths, capture_output=True, text=True, env=env)
@@ -225,10 +192,43 @@ def test_image_readers_with_crafted_headers_under_asan_ubsan(tmp_path):
         'pnm_lies_plain.pgm': b'P2 40000 40000 255\n1 2 3',
     }
     files.update(lies)
+    # Headers that lie about sizes no file of a few hundred bytes can hold (ADVICE round 3): nothing may be allocated,
+    # reserved or zero-filled on a header's word.  These are also run by an unsanitized build under a 1 GiB address-space
+    # limit below: an allocation the size of the lie would fail there (or, unlimited, zero-fill gigabytes).
+    def tif(w, h, comp, spp, bits, data):
+        ents = [(256, 4, 1, w), (257, 4, 1, h), (258, 3, 1, bits), (259, 3, 1, comp), (262, 3, 1, 2 if spp >= 3 else 1), (273, 4, 1, 8 + 2 + 12 * 10 + 4),
+                (277, 3, 1, spp), (278, 4, 1, h), (279, 4, 1, len(data)), (284, 3, 1, 1)]
+        ifd = struct.pack('<H', len(ents)) + b''.join(struct.pack('<HHII', t, ty, n, v) for t, ty, n, v in ents) + struct.pack('<I', 0)
+        return b'II*\0' + struct.pack('<I', 8) + ifd + data
+    gif_1x1 = b'\x2C' + struct.pack('<HHHHB', 0, 0, 1, 1, 0x80) + bytes(6) + bytes([2, 2, 0x4C, 0x01, 0]) + b'\x3B'
+    lies = {
+        'gif_blank_screen.gif': b'GIF89a' + struct.pack('<HHBBB', 0xFFFF, 0xFFFF, 0, 0, 0) + gif_1x1,            # 40 bytes, 12.9 GB of screen
+        'gif_blank_screen2.gif': b'GIF89a' + struct.pack('<HHBBB', 20000, 20000, 0, 0, 0) + gif_1x1,
+        'gif_frame_lies.gif': b'GIF89a' + struct.pack('<HHBBB', 9000, 9000, 0, 0, 0) + b'\x2C' + struct.pack('<HHHHB', 0, 0, 9000, 9000, 0x80) + bytes(6) + bytes([2, 2, 0x4C, 0x01, 0]) + b'\x3B',
+        'tif_zip_lies.tif': tif(60000, 60000, 8, 8, 16, bytes(40)), 'tif_lzw_lies.tif': tif(60000, 60000, 5, 8, 16, bytes(40)),
+        'tif_pb_lies.tif': tif(60000, 60000, 32773, 3, 8, bytes(40)), 'tif_raw_lies.tif': tif(60000, 60000, 1, 3, 8, bytes(40)),
+        'tga_rle_lies.tga': bytes([0, 0, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0xFF, 0xFF, 0xFF, 0xFF, 32, 0, 0xFF, 1, 2, 3, 4]),
+        'tga_raw_lies.tga': bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0xFF, 0xFF, 0xFF, 0xFF, 32, 0]) + bytes(64),
+        'qoi_lies.qoi': b'qoif' + struct.pack('>IIBB', 40000, 40000, 3, 0) + bytes([0xFD] * 20) + bytes(8),
+        'ff_lies.ff': b'farbfeld' + struct.pack('>II', 40000, 40000) + bytes(64),
+        'bmp_lies.bmp': bmp(40000, 40000, 24, body=bytes(100)), 'pnm_lies.ppm': b'P6 40000 40000 255\n' + bytes(100), 'pnm_lies.pbm': b'P4 60000 60000\n' + bytes(100),
+        'pnm_lies_plain.pgm': b'P2 40000 40000 255\n1 2 3',
+    }
+    files.update(lies)
     for name, data in files.items():
         p = str(tmp_path / name)
         open(p, 'wb').write(data)
         paths.append(p)
+    plain = str(tmp_path / 'image_plain')
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-I' + csrc, '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'native', 'image_asan.cpp'),
+                           os.path.join(csrc, 'png.cpp'), os.path.join(csrc, 'image.cpp'), '-o', plain, '-lz'])
+    import resource
+
+    def limit():
+        resource.setrlimit(resource.RLIMIT_AS, (1 << 30, 1 << 30))
+    out = subprocess.run([plain] + [str(tmp_path / n) for n in lies] + [paths[0]], capture_output=True, text=True, preexec_fn=limit)
+    assert out.returncode == 0 and 'images ok' in out.stdout and 'out of memory' not in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count('rc 0') == 1                                    # only the good file decodes
     plain = str(tmp_path / 'image_plain')
     subprocess.check_call(['g++', '-std=c++17', '-O1', '-I' + csrc, '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'native', 'image_asan.cpp'),
                            os.path.join(csrc, 'png.cpp'), os.path.join(csrc, 'image.cpp'), '-o', plain, '-lz'])
