@@ -561,6 +561,32 @@ def test_textured_scene(chess_bytes):
     gpu_vs_oracle(data, 1024, 256, [(0, 256)], textures=tex)
 
 
+def test_texel_addressing_inside_outside_and_on_a_very_tall_image():
+    """`fun_color_channel` (/root/reference/src/textures.rs:27-36) around every border: coordinates below zero, exactly on the last
+    texel, one past it, far past it, NaN (0/0 on one row) and +-inf (1/0), for a small image and for one that is 2^24 + 5 texels
+    tall -- the specialised kernels read images below 2 GiB with sides below 2^24 through a buffer resource (a lane outside
+    the image is given an offset past the resource's end and reads 0: the hardware's range check instead of a select),
+    others through 64-bit addresses: both paths here, and the interpreters, against the oracle; u8 and f64 planes."""
+    from marayb import app, channel, image_height, image_width
+    rng = np.random.default_rng(11)
+    small = rng.integers(0, 256, (23, 37, 3), dtype=np.uint8)
+    tall_h = (1 << 24) + 5
+    tall = np.zeros((tall_h, 1, 3), dtype=np.uint8)
+    tall[:, 0, 0] = np.arange(tall_h) % 251
+    tall[:, 0, 1] = (np.arange(tall_h) // 7) % 256
+    tall[-6:, 0, 2] = [9, 8, 7, 6, 5, 4]
+    w, h = 96, 8
+    u = add(x(), neg(nat(20)))                                   # -20 .. 75 across the small image's 37 columns
+    v = add(mul(y(), nat(4)), neg(nat(3)))                       # -3 .. 25 across its 23 rows
+    pole = mul(u, recip(sub(y(), nat(2))))                       # row 2: +-inf and, at u = 0, NaN
+    # rows of the tall image: the last ones, reached by x; one past the end; the first
+    vt = add(nat(tall_h - 40), x())
+    c = [max_(app(channel(0, 0), u, v), mul(app(channel(0, 0), pole, v), div(nat(1), nat(2)))),
+         add(app(channel(1, 0), nat(0), vt), mul(app(channel(1, 1), sub(y(), nat(4)), mul(x(), nat(100000))), div(nat(1), nat(4)))),
+         add(app(channel(1, 2), nat(0), vt), add(app(channel(0, 2), v, u), mul(app(image_height(1), x(), y()), div(nat(1), nat(1 << 20)))))]
+    gpu_vs_oracle(encode((w, h), c), w, h, [(0, h)], textures=[small, tall])
+
+
 def test_all_ops_scene_bit_exact():
     """Config 3b: every computing variant of Expr (sin, exp, ln, sqrt, abs, recip ...) - f64 planes bit-exact."""
     data = encode((640, 96), scenes.all_ops(640, 96))
