@@ -185,3 +185,44 @@ def curved_soup(seed, n, w, h, mixed=False):
         return [mul(m, nat(255)), mul(max_(m, mul(grad, div(nat(1), nat(2)))), nat(255)), mul(add(mul(m, div(nat(3), nat(4))), mul(grad, div(nat(1), nat(4)))), nat(255))]
     return [mul(paint(shapes), nat(255)), mul(max_(paint(shapes[::2]), mul(grad, div(nat(1), nat(2)))), nat(255)),
             mul(add(mul(paint(shapes[1::2] or shapes), div(nat(3), nat(4))), mul(grad, div(nat(1), nat(4)))), nat(255))]
+
+
+def product_soup(seed, n, w, h):
+    """n shapes whose edge tests are Steps of PRODUCTS, SQUARES, ROOTS and RECIPROCALS of terms that are monotone in x and in y --
+    what the lowering's monotonicity rule for two varying factors, its square and abs rules and the end-point bounds decide
+    on (lower.cpp: monotonicity, RowBounds): (x + a)(x + b) <= k, (x + a)(y + b) >= k, sqrt(x + a)(y + b) <= k, products of
+    two non-positive factors, a factor that changes sign inside the image (no monotone bound: interval corners), 1/(x + a)
+    against y.  Each shape carries a Step(Sin) pattern, so that skipping it matters."""
+    rng = random.Random(0xBEEF + seed)
+    shapes = []
+    for _ in range(n):
+        a, b = rng.randrange(1, 40), rng.randrange(1, 40)
+        k = rng.randrange(1, w * h // 4)
+        kind = rng.randrange(8)
+        X, Y = x(), y()
+        if kind == 0:
+            e_ = sub(nat(k), mul(add(X, nat(a)), add(X, nat(b))))                          # (x+a)(x+b) <= k: both factors >= 0, increasing
+        elif kind == 1:
+            e_ = sub(mul(add(X, nat(a)), add(Y, nat(b))), nat(k))                          # (x+a)(y+b) >= k
+        elif kind == 2:
+            e_ = sub(nat(k), mul(sqrt(add(X, nat(a))), add(Y, nat(b))))                     # sqrt(x+a)(y+b) <= k
+        elif kind == 3:
+            e_ = sub(nat(k), mul(neg(add(X, nat(a))), neg(add(Y, nat(b)))))                 # two non-positive factors
+        elif kind == 4:
+            e_ = sub(nat(k), mul(sub(X, nat(rng.randrange(0, w))), sub(X, nat(rng.randrange(0, w)))))      # factors that change sign inside the image
+        elif kind == 5:
+            c = rng.randrange(0, w)
+            e_ = sub(nat(rng.randrange(1, 60) ** 2), add(mul(sub(X, nat(c)), sub(X, nat(c))), mul(sub(Y, nat(b)), sub(Y, nat(b)))))   # a disc, written with squares
+        elif kind == 6:
+            e_ = sub(mul(recip(add(X, nat(a))), nat(k)), add(Y, nat(b)))                    # k / (x+a) >= y + b
+        else:
+            e_ = sub(nat(k), mul(mul(add(X, nat(a)), add(X, nat(b))), add(Y, nat(1))))      # a product of three
+        inside = step(e_)
+        from marayb import chess
+        pattern = subst_xy(chess(rng.choice([2, 3])), mul(add(X, Y), div(nat(1), nat(rng.randrange(5, 19)))), mul(sub(X, Y), div(nat(1), nat(rng.randrange(5, 19)))))
+        shapes.append(min_(inside, pattern))
+    acc = shapes[0]
+    for t in shapes[1:]:
+        acc = max_(acc, t)
+    grad = mul(add(x(), y()), div(nat(1), nat(w + h)))
+    return [mul(acc, nat(255)), mul(max_(acc, mul(grad, div(nat(1), nat(2)))), nat(255)), mul(add(mul(acc, div(nat(1), nat(2))), mul(grad, div(nat(1), nat(2)))), nat(255))]

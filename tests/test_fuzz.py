@@ -115,6 +115,26 @@ def test_curved_soups_lowering_vs_oracle():
         assert same_f64(tape_eval.render_rows_waves(tape, w, 0, h, tile=64, yrows=32), want64), seed
 
 
+def test_product_soups_lowering_vs_oracle():
+    """Shapes whose edge tests are Steps of products, squares, roots and reciprocals of terms monotone in x and y
+    (fuzz_scenes.product_soup): the lowering's rule for a product of two varying sign-definite factors, its square rule
+    and the end-point bounds decide what a span or a rectangle skips.  Every pixel against the oracle with SKIP ops
+    ignored, taken per wavefront, per span and per rectangle.  (A sweep of 240 more: 0 mismatches, round 4.)"""
+    from fuzz_scenes import product_soup
+    w, h = 192, 48
+    for seed in range(500, 506):
+        data = encode((w, h), product_soup(seed, 12, w, h))
+        tape = M.Scene(data).lower()
+        n_guards, n_read_y = tape_eval.guards_reading_y(tape)
+        assert n_guards >= 10 and n_read_y == 0, (seed, n_guards, n_read_y)
+        _, want64 = OScene(data).render_rows(w, h, 0, h)
+        assert same_f64(tape_eval.render_rows(tape, w, 0, h), want64), seed
+        assert same_f64(tape_eval.render_rows_waves(tape, w, 0, h), want64), seed
+        assert same_f64(tape_eval.render_rows_waves(tape, w, 0, h, tile=64), want64), seed
+        assert same_f64(tape_eval.render_rows_waves(tape, w, 0, h, tile=64, yrows=8), want64), seed
+        assert same_f64(tape_eval.render_rows_waves(tape, w, 0, h, tile=64, yrows=32), want64), seed
+
+
 def _soups_on_the_gpu(cases, w, h):
     """cases: (name, scene bytes).  The three evaluators agree on every pixel (u8 and f64 planes); the GUARD-FREE lowering
     of the same scene (no SKIP op, no guard, no rebalanced chain, no private region: every pixel evaluates the whole DAG
@@ -169,6 +189,14 @@ def test_curved_soups_gpu_vs_oracle():
     for _, data in cases:
         assert tape_eval.guards_reading_y(M.Scene(data).lower())[1] == 0
     _soups_on_the_gpu(cases, w, h)
+
+
+@pytest.mark.gpu
+def test_product_soups_gpu_vs_oracle():
+    """Six soups of 30 shapes bounded by products, squares, roots and reciprocals of monotone terms; see _soups_on_the_gpu."""
+    from fuzz_scenes import product_soup
+    w, h = 1024, 200
+    _soups_on_the_gpu([('products %d' % seed, encode((w, h), product_soup(seed, 30, w, h))) for seed in range(600, 606)], w, h)
 
 
 @pytest.mark.gpu
