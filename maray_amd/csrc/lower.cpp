@@ -958,10 +958,14 @@ struct Lowerer {
         sec.sched.push_back(self);
     }
 
-    void build(Section &sec, bool pixel) {
+    // scheduled: sec.sched holds the section's schedule already (the dry run that numbered the y values made it: the schedule
+    // does not depend on their numbers, only the encoding does)
+    void build(Section &sec, bool pixel, bool scheduled = false) {
         const size_t N = g.n.size();
-        prepare(sec);
-        for (auto &o : sec.outs) if (in_section[o.first]) visit(o.first, sec);
+        if (!scheduled) {
+            prepare(sec);
+            for (auto &o : sec.outs) if (in_section[o.first]) visit(o.first, sec);
+        }
 
         // Final item list: OUT ops go right after the node they read (never inside a skipped
         // region: a node with an OUT is not exclusive to anything).
@@ -1335,6 +1339,7 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         for (size_t i = 0; i < N; i++) number((int32_t)i);
         info.n_yvals = k;
         if (k > MARAY_MAX_INDEX + 1) throw Error{MARAY_E_LIMIT, "more than 16384 row values"};
+        pix.sched = std::move(dry.sched);           // = the PIXEL section's schedule (the nodes of the section are the same: the guards' cones joined the ROW section)
     }
     lap("typing, dry schedule");
     std::vector<uint8_t> is_pix(N, 0);
@@ -1351,6 +1356,7 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         L.build(row, false);
         lap("ROW section");
         L.in_section = is_pix;
+        pix.sched.clear();                      // (serial mode schedules the section again: the reference the reuse below is tested against)
         L.build(pix, true);
         lap("PIXEL section");
     } else {
@@ -1374,7 +1380,7 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         struct Join { pthread_t &t; bool on; ~Join() { if (on) pthread_join(t, nullptr); } } join{th, threaded};
         if (!threaded) RowJob::main(&job);
         L.in_section = is_pix;
-        L.build(pix, true);
+        L.build(pix, true, /*scheduled=*/true);
         if (threaded) { pthread_join(th, nullptr); join.on = false; }
         if (job.error) std::rethrow_exception(job.error);
         // pool = [before | ROW's new | PIXEL's new that the ROW section did not bring]
