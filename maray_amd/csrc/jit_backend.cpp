@@ -60,7 +60,6 @@ struct JitBackend final : Backend {
     uint32_t n_cu = 256;
     bool wide_all = false;              // the whole section runs four pixels per lane (jit_wide_general)
     bool rows2 = false;                 // busy tiles two rows per wavefront (JitCode::rows2)
-    bool rpw1 = false;                  // MARAY_RPW1=1 (measurement): a two-row kernel launched one row per wavefront
     unsigned k_tiles = 0;               // MARAY_JIT_TILES: tiles per wavefront (0 = by launch size), read once when the context is created
     bool has_sin = false;               // some Sin argument is not proven bounded: tiles may be deferred to `slow`
     hipStream_t last_stream = nullptr; bool have_last = false;      // the stream of the last launch (see launch())
@@ -121,7 +120,6 @@ struct JitBackend final : Backend {
         n_row_chunks = code->n_row_chunks; n_gjobs = code->n_gjobs;
         wide_all = jit_wide_general(prog, code->n_gwords);
         rows2 = code->rows2;
-        if (const char *e_ = getenv("MARAY_RPW1")) rpw1 = e_[0] == '1';
         if (has_sin) slow = make_tape_backend(dev, prog, tex, n_tex, false);     // drains the tiles the pixel kernel defers; other programs never defer
         P = prog;
         P.consts = nullptr; P.row_ops = nullptr; P.pix_ops = nullptr;
@@ -238,7 +236,7 @@ struct JitBackend final : Backend {
                                   : (n_tiles <= 4 * device_slots ? 1 : n_tiles <= 16 * device_slots ? 2 : 4);
         // two rows per wavefront: when the launch's guard groups have an even number of rows (a pair then lies inside one group);
         // the strip is half as long, so that a wavefront owns as many pixels as it would with one row
-        const unsigned rpw = (rows2 && !rpw1 && yrows >= 2 && yrows % 2 == 0) ? 2u : 1u;
+        const unsigned rpw = (rows2 && yrows >= 2 && yrows % 2 == 0) ? 2u : 1u;
         if (rpw == 2 && tiles > 1) tiles /= 2;
         if (k_tiles) tiles = std::min(64u, k_tiles);
         if (n_gwords && n_gwords <= GW_INLINE_MAX) tiles = std::min(tiles, 64u / (n_gwords * guard_sub));      // a strip's guard words: one per lane
