@@ -96,12 +96,14 @@ def main():
     args = ap.parse_args()
 
     fake_world = os.environ.get('MARAY_BENCH_FAKE_WORLD')
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and not fake_world:
+    # (an environment that exports WORLD_SIZE=1 to everything it starts is not a launcher either; our own ranks carry a mark)
+    if args.gpus > 1 and os.environ.get('WORLD_SIZE', '1') in ('', '1') and 'MARAY_BENCH_RANK_OF' not in os.environ and not fake_world:
         # `python bench.py --gpus N` with no launcher around it: this process becomes the launcher.  It has imported
         # neither torch nor the library and never touches HIP; the ranks are fresh children (never an exec), one per
         # GPU, environment as torch.distributed.run sets it.  Rank 0's JSON line is relayed; any rank's failure is ours.
         from maray_amd.sharding import launch_ranks
-        rc, out = launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, timeout=args.rank_timeout)
+        rc, out = launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, timeout=args.rank_timeout,
+                               env=dict(os.environ, MARAY_BENCH_RANK_OF=str(os.getpid())))
         lines = [ln for ln in out.splitlines() if ln.startswith('{')]
         for ln in out.splitlines():
             if not ln.startswith('{'):
