@@ -332,11 +332,15 @@ std::string jit_source_rows(const maray_program &P, uint32_t *n_chunks_out, uint
 bool jit_wide_general(const maray_program &P, uint32_t n_gwords)        // n_gwords = jit_guard_words(P) (a walk over the ROW tape: the caller has it)
 {
     bool heavy = false;
+    // texture lookups do not keep a small program from the four-wide form (round 4: four gathers per lane in flight, the scalar
+    // unit's share paid once per 256 pixels: config 5 41.5 -> 39.3 us); MARAY_JIT_WIDE_APP=0: one pixel per lane (ablation)
+    const char *e_ = getenv("MARAY_JIT_WIDE_APP");
+    const bool wide_app = !(e_ && e_[0] == '0');
     for (uint32_t i = 0; i < P.n_pix_ops; i++) {
         const uint32_t op = MARAY_INS_OP(P.pix_ops[i]);
-        heavy |= op == MARAY_OP_SIN || op == MARAY_OP_EXP || op == MARAY_OP_LN || op == MARAY_OP_STEPSIN || op == MARAY_OP_APP;
+        heavy |= op == MARAY_OP_SIN || op == MARAY_OP_EXP || op == MARAY_OP_LN || op == MARAY_OP_STEPSIN || (op == MARAY_OP_APP && !wide_app);
     }
-    return n_gwords == 0 && !heavy && P.n_pix_slots <= 6 && P.n_pix_ops <= 256;
+    return n_gwords == 0 && !heavy && P.n_pix_slots <= (wide_app ? 12u : 6u) && P.n_pix_ops <= 256;
 }
 
 // Two rows per wavefront in the busy tiles (jit_source): a program whose shapes are guarded per rectangle of an even number

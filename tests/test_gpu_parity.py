@@ -554,11 +554,19 @@ def test_cli_renders_chess_png(tmp_path, chess_bytes):
     assert r.returncode == 1 and 'Error' in r.stderr
 
 
-def test_textured_scene(chess_bytes):
-    """Config 5 at reduced size vs the oracle, full size through its integer-lookup property."""
+def test_textured_scene(chess_bytes, monkeypatch):
+    """Config 5 at reduced size vs the oracle, full size through its integer-lookup property; the specialised kernel in its
+    default form (four pixels per lane: a small program without guards, texture lookups included since round 4), one pixel
+    per lane, and with a call of mr_app per App op (round 3's form)."""
     tex = scenes.textures(scale=4)
     data = encode((1024, 256), scenes.textured(1024))
     gpu_vs_oracle(data, 1024, 256, [(0, 256)], textures=tex)
+    for env in ({'MARAY_JIT_WIDE_APP': '0'}, {'MARAY_JIT_WIDE_APP': '0', 'MARAY_JIT_TEXEL_ONCE': '0'}, {'MARAY_JIT_TEXEL_ONCE': '0'}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        gpu_vs_oracle(data, 1024, 256, [(0, 256)], textures=tex, backends=[M.BACKEND_JIT])
+        for k in env:
+            monkeypatch.delenv(k)
 
 
 def test_texel_addressing_inside_outside_and_on_a_very_tall_image():
