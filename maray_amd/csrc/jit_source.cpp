@@ -390,7 +390,7 @@ std::string jit_source(const maray_program &P, int min_waves)
     // region's test and branch cost that unit more than its ops cost the vector one (chess board, us per 16.7 Mpx, with
     // guards per 256 x 8 pixels: none ignored 111, 24: 104; with guards per 64 x 32: 8 / 12 / 16 ... 32 / 64 / 200:
     // 83.3 / 82.4 / 84.7 / 85.4 / 128).
-    E.min_region = 12;
+    E.min_region = 24;          // (round 4: from 12; pixel kernel / step / board 27.34 / 34.02 / 60.9 against 27.6 / 34.2-34.4 / 61.2 us, the same sign in round 3's table)
     if (const char *e_ = getenv("MARAY_JIT_MIN_REGION")) E.min_region = (uint32_t)atoi(e_);
     E.ybool = jit_bool_yvals(P);
     if (const char *e_ = getenv("MARAY_JIT_FUSE_CMP")) E.fuse_cmp = e_[0] != '0';

@@ -897,7 +897,7 @@ def test_specialised_kernel_variants_selected_by_tuning_knobs(chess_bytes, monke
     tape = M.Scene(chess_bytes).lower()
     for env in ({'MARAY_JIT_TILES': '1'}, {'MARAY_JIT_TILES': '5'}, {'MARAY_JIT_GUARD_W': '256', 'MARAY_JIT_GUARD_H': '8'},
                 {'MARAY_JIT_GUARD_W': '128', 'MARAY_JIT_GUARD_H': '16', 'MARAY_JIT_TILES': '3'}, {'MARAY_JIT_GUARD_W': '64', 'MARAY_JIT_GUARD_H': '128'},
-                {'MARAY_JIT_MIN_REGION': '0'}, {'MARAY_JIT_MIN_REGION': '100000'}, {'MARAY_JIT_ROW_GUARDS': '0'},
+                {'MARAY_JIT_MIN_REGION': '0'}, {'MARAY_JIT_MIN_REGION': '12'}, {'MARAY_JIT_MIN_REGION': '100000'}, {'MARAY_JIT_ROW_GUARDS': '0'},
                 {'MARAY_JIT_HELPER': '0', 'MARAY_JIT_OPT': '-O1'}, {'MARAY_JIT_ROWS2': '1'}, {'MARAY_JIT_ROWS2': '1', 'MARAY_JIT_TILES': '3'},
                 {'MARAY_JIT_ROWS2': '0'}, {'MARAY_JIT_TEXEL_ONCE': '0'}):
         for k, v in env.items():
