@@ -19,7 +19,7 @@ for c in "board chess board" "sky chess sky" "textured textured x" "allops allop
   bash tools/pmc_crop.sh r4_$1 $2 $3 > gpurun_out/crop_r4_$1.log 2>&1 || tail -3 gpurun_out/crop_r4_$1.log
 done
 echo "== ablations"
-timeout -k 10 600 python tools/exp_pixels.py "default:" "Step(x + k) as add + compare (round 3):MARAY_JIT_FUSE_CMP=0" "two rows per wavefront, 2 tiles:MARAY_JIT_ROWS2=1,MARAY_JIT_TILES=2" "two rows per wavefront, 1 tile:MARAY_JIT_ROWS2=1" "tree walked as written (round 2):MARAY_JIT_REDUCE=0" "tiles 1:MARAY_JIT_TILES=1" "tiles 3:MARAY_JIT_TILES=3" "tiles 4:MARAY_JIT_TILES=4" "row guards off:MARAY_JIT_ROW_GUARDS=0" "guards 256x8 (round 1):MARAY_JIT_GUARD_W=256,MARAY_JIT_GUARD_H=8" "guards 64x16:MARAY_JIT_GUARD_H=16" "guards 64x64:MARAY_JIT_GUARD_H=64" "regions from 24:MARAY_JIT_MIN_REGION=24" "default again:" > gpurun_out/ablations_r4.jsonl 2> gpurun_out/ablations_r4.err; cat gpurun_out/ablations_r4.jsonl | cut -c1-260
+timeout -k 10 600 python tools/exp_pixels.py "default:" "Step(x + k) as add + compare (round 3):MARAY_JIT_FUSE_CMP=0" "two rows per wavefront, 2 tiles:MARAY_JIT_ROWS2=1,MARAY_JIT_TILES=2" "two rows per wavefront, 1 tile:MARAY_JIT_ROWS2=1" "tree walked as written (round 2):MARAY_JIT_REDUCE=0" "tiles 1:MARAY_JIT_TILES=1" "tiles 3:MARAY_JIT_TILES=3" "tiles 4:MARAY_JIT_TILES=4" "row guards off:MARAY_JIT_ROW_GUARDS=0" "guards 256x8 (round 1):MARAY_JIT_GUARD_W=256,MARAY_JIT_GUARD_H=8" "guards 64x16:MARAY_JIT_GUARD_H=16" "guards 64x64:MARAY_JIT_GUARD_H=64" "regions from 12 (round 3):MARAY_JIT_MIN_REGION=12" "small textured programs one pixel per lane:MARAY_JIT_WIDE_APP=0" "default again:" > gpurun_out/ablations_r4.jsonl 2> gpurun_out/ablations_r4.err; cat gpurun_out/ablations_r4.jsonl | cut -c1-260
 echo "== other configs"
 python tools/bench_configs.py > gpurun_out/other_configs_r4.json 2>/dev/null; head -c 300 gpurun_out/other_configs_r4.json
 MARAY_JIT_TEXEL_ONCE=0 python tools/bench_configs.py > gpurun_out/other_configs_r4_texel_per_app.json 2>/dev/null
