@@ -69,32 +69,49 @@ inline double rs_min(double a, double b)
     return a < b ? a : b;
 }
 
-struct KeyHash {
-    size_t operator()(const std::array<uint64_t, 3> &k) const {
-        uint64_t h = k[0] * 0x9e3779b97f4a7c15ULL;
-        h ^= (k[1] + 0x7f4a7c15ULL + (h << 6) + (h >> 2));
-        h *= 0xff51afd7ed558ccdULL;
-        h ^= (k[2] + (h << 6) + (h >> 2));
-        return (size_t)(h ^ (h >> 29));
-    }
-};
-
+// Hash-consing table of the DAG: open addressing over node ids (the key of a slot is read from the node it names).  A
+// large scene interns 60,000 nodes three or four times over (the scene, its row bounds over x and over y, the private
+// copies): in a node-based map that was a sixth of a lowering.
 struct Dag {
     std::vector<DNode> n;
-    std::unordered_map<std::array<uint64_t, 3>, int32_t, KeyHash> map;
+    std::vector<int32_t> table;          // node id + 1, 0 = empty; size a power of two, at most half full
     uint32_t folded = 0;
     bool commute = true;
     bool fuse = true;
 
+    static uint64_t hash(const DNode &d) {
+        uint64_t h = ((uint64_t)d.op | ((uint64_t)d.aux << 8) | ((uint64_t)d.inst << 32)) * 0x9e3779b97f4a7c15ULL;
+        h ^= ((((uint64_t)(uint32_t)d.a << 32) | (uint32_t)d.b) + 0x7f4a7c15ULL + (h << 6) + (h >> 2));
+        h *= 0xff51afd7ed558ccdULL;
+        h ^= ((d.op == D_CONST ? bits_of(d.cval) : 0) + (h << 6) + (h >> 2));
+        return h ^ (h >> 29);
+    }
+    static bool same(const DNode &x, const DNode &y) {
+        return x.op == y.op && x.aux == y.aux && x.inst == y.inst && x.a == y.a && x.b == y.b && (x.op != D_CONST || bits_of(x.cval) == bits_of(y.cval));
+    }
+    void reserve(size_t nodes) {
+        n.reserve(nodes);
+        size_t want = 1024;
+        while (want < 2 * nodes) want *= 2;
+        if (want > table.size()) rehash(want);
+    }
+    void rehash(size_t size) {
+        table.assign(size, 0);
+        for (size_t id = 0; id < n.size(); id++) {
+            size_t at = hash(n[id]) & (size - 1);
+            while (table[at]) at = (at + 1) & (size - 1);
+            table[at] = (int32_t)id + 1;
+        }
+    }
     int32_t intern(const DNode &d) {
-        std::array<uint64_t, 3> k = {(uint64_t)d.op | ((uint64_t)d.aux << 8) | ((uint64_t)d.inst << 32), ((uint64_t)(uint32_t)d.a << 32) | (uint32_t)d.b,
-                                     d.op == D_CONST ? bits_of(d.cval) : 0};
-        auto it = map.find(k);
-        if (it != map.end()) return it->second;
+        if (2 * (n.size() + 1) > table.size()) rehash(table.empty() ? 1024 : 2 * table.size());
+        const size_t mask = table.size() - 1;
+        size_t at = hash(d) & mask;
+        for (; table[at]; at = (at + 1) & mask)
+            if (same(n[table[at] - 1], d)) return table[at] - 1;
         n.push_back(d);
-        int32_t id = (int32_t)n.size() - 1;
-        map.emplace(k, id);
-        return id;
+        table[at] = (int32_t)n.size();
+        return (int32_t)n.size() - 1;
     }
     int32_t konst(double v) {
         if (v != v) v = NAN;   // one canonical NaN
@@ -754,6 +771,7 @@ struct Lowerer {
     // membership by stamp instead of hash sets (the scheduler asks for the cone of every AND / OR it meets: chess lowers
     // in a tenth of the time): a node is in the set computed last iff its stamp equals the set's epoch
     std::vector<uint32_t> seen_stamp, cone_stamp;
+    std::vector<std::pair<int32_t, int>> reach_stack;      // (reach(): node, operands walked)
     uint32_t seen_epoch = 0, cone_epoch = 0;
     bool in_cone(int32_t v) const { return cone_stamp[v] == cone_epoch; }
     std::unordered_map<uint64_t, uint32_t> const_index;
@@ -812,18 +830,29 @@ struct Lowerer {
         for (auto &o : sec.outs) if (in_section[o.first]) users_idx[fill[o.first]++] = -1;
     }
 
-    // Unvisited section nodes reachable from `root`, ascending (= topological) order.
+    // Unvisited section nodes reachable from `root`, producers before consumers (the post-order of a depth-first walk: a node
+    // after everything it reads).  The cones below walk it backwards and need exactly that -- every user of a node before the
+    // node -- and are sets, so any such order gives the same cone; sorting the nodes by id (ascending ids are one such
+    // order) was an eighth of a large scene's lowering.
     std::vector<int32_t> reach(int32_t root) {
-        std::vector<int32_t> r, st{root};
+        std::vector<int32_t> r;
         ++seen_epoch;
-        while (!st.empty()) {
-            int32_t v = st.back(); st.pop_back();
-            if (v < 0 || !in_section[v] || visited[v] || seen_stamp[v] == seen_epoch) continue;
-            seen_stamp[v] = seen_epoch;
+        auto fresh = [&](int32_t v) { return v >= 0 && in_section[v] && !visited[v] && seen_stamp[v] != seen_epoch; };
+        if (!fresh(root)) return r;
+        reach_stack.clear();
+        reach_stack.push_back({root, 0});
+        seen_stamp[root] = seen_epoch;
+        while (!reach_stack.empty()) {
+            auto &top = reach_stack.back();
+            const int32_t v = top.first;
+            if (top.second < 2) {
+                const int32_t c = top.second++ == 0 ? g.n[v].a : g.n[v].b;
+                if (fresh(c)) { seen_stamp[c] = seen_epoch; reach_stack.push_back({c, 0}); }
+                continue;
+            }
             r.push_back(v);
-            st.push_back(g.n[v].a); st.push_back(g.n[v].b);
+            reach_stack.pop_back();
         }
-        std::sort(r.begin(), r.end());
         return r;
     }
 
@@ -917,18 +946,22 @@ struct Lowerer {
             // orientation: the operand with the smaller exclusive cone guards the other one
             size_t best = 0;
             int32_t guard = -1, body = -1;
+            std::vector<int32_t> r_body;
             for (int o = 0; o < 2; o++) {
                 const int32_t bq = o ? d.a : d.b, gq = o ? d.b : d.a;
                 if (!in_section[bq] || visited[bq] || g.n[bq].op >= D_CONST) continue;
-                const std::vector<int32_t> r = reach(bq);
+                std::vector<int32_t> r = reach(bq);
                 const size_t sz = exclusive_cone(bq, i, r);
-                if (sz >= MIN_REGION && sz > best) { best = sz; guard = gq; body = bq; }
+                if (sz >= MIN_REGION && sz > best) { best = sz; guard = gq; body = bq; r_body.swap(r); }
             }
             if (guard >= 0 && g.n[guard].op != D_CONST) {
                 visited[i] = 1;
                 visit(guard, sec);
                 if (!visited[body]) {
-                    const std::vector<int32_t> r = reach(body);
+                    // reach(body) now = what it was before the guard was scheduled, less the nodes scheduled since: a node that
+                    // got scheduled took everything it reads with it, so what is left is still reached through unscheduled nodes
+                    r_body.erase(std::remove_if(r_body.begin(), r_body.end(), [&](int32_t v) { return visited[v] != 0; }), r_body.end());
+                    const std::vector<int32_t> &r = r_body;
                     const size_t cone = exclusive_cone(body, i, r);
                     if (cone >= MIN_REGION && in_cone(body)) {
                         visit_shared(r, sec);                                     // shared nodes: computed unconditionally
@@ -1137,7 +1170,7 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
     }
     lap("rebalance");
     const size_t N0 = g.n.size();
-    if (row_guards) { g.map.reserve(4 * N0 + 1024); g.n.reserve(4 * N0 + 1024); }      // the row bounds grow the DAG about threefold
+    if (row_guards) g.reserve(4 * N0 + 1024);      // the row bounds grow the DAG about threefold
     const uint32_t folded_scene = g.folded;     // constant ops folded in the scene itself (the row bounds fold more)
     std::vector<int32_t> rowub;
     if (row_guards) {

@@ -203,17 +203,39 @@ struct PlainKeyHash {
 struct Interner {
     Scene &out;
     std::unordered_map<std::string, int32_t> map;             // Let / Decor nodes: the key spells out their context / tokens
-    std::unordered_map<PlainKey, int32_t, PlainKeyHash> plain;
+    // plain nodes: open addressing over (key, node id + 1) -- a tenth of a large scene's lowering was this table as a node-based map
+    std::vector<std::pair<PlainKey, int32_t>> plain;
+    size_t n_plain = 0;
 
     static void put(std::string &k, uint64_t v) { k.append((const char *)&v, 8); }
+
+    void reserve_plain(size_t nodes) {
+        size_t want = 1024;
+        while (want < 2 * nodes) want *= 2;
+        if (want > plain.size()) rehash(want);
+    }
+    void rehash(size_t size) {
+        std::vector<std::pair<PlainKey, int32_t>> old(size);
+        old.swap(plain);
+        for (const auto &e : old) {
+            if (!e.second) continue;
+            size_t at = PlainKeyHash()(e.first) & (size - 1);
+            while (plain[at].second) at = (at + 1) & (size - 1);
+            plain[at] = e;
+        }
+    }
 
     int32_t intern(const Node &n, const Ctx *ctx, const std::vector<Token> *toks) {
         if (!ctx && !toks) {
             const PlainKey pk{{n.tag, n.u, n.app, (uint64_t)(int64_t)n.a, (uint64_t)(int64_t)n.b}};
-            auto it = plain.find(pk);
-            if (it != plain.end()) return it->second;
+            if (2 * (n_plain + 1) > plain.size()) rehash(plain.empty() ? 1024 : 2 * plain.size());
+            const size_t mask = plain.size() - 1;
+            size_t at = PlainKeyHash()(pk) & mask;
+            for (; plain[at].second; at = (at + 1) & mask)
+                if (plain[at].first == pk) return plain[at].second - 1;
             const int32_t id = out.add(n);
-            plain.emplace(pk, id);
+            plain[at] = {pk, id + 1};
+            n_plain++;
             return id;
         }
         std::string k;
@@ -251,7 +273,7 @@ struct Fixer {
     std::unordered_map<int32_t, uint64_t> ids;   // VarFixer::ids (:10)
     uint64_t var_count = 0;                      // VarFixer::var_count (:12)
 
-    Fixer(const Scene &in_, Scene &out) : in(in_), I{out, {}, {}} { I.plain.reserve(in_.nodes.size()); }
+    Fixer(const Scene &in_, Scene &out) : in(in_), I{out, {}, {}} { I.reserve_plain(in_.nodes.size()); }
 
     // verbatim structural copy (Decor tokens are carried over unfixed, :67)
     int32_t copy(int32_t e) {
