@@ -265,11 +265,16 @@ Ival ival_mul(const Ival &a, const Ival &b)
     return r;
 }
 
-std::vector<Ival> intervals(const Dag &g)
+// (`have`: the intervals of the first nodes of a DAG that has grown since -- a node's interval depends on its operands' only)
+std::vector<Ival> intervals(const Dag &g, const std::vector<Ival> *have = nullptr)
 {
     const double dmax = (double)MARAY_DOMAIN_MAX - 1.0;
-    std::vector<Ival> v(g.n.size());
-    for (size_t i = 0; i < g.n.size(); i++) {        // children are interned before their parents
+    std::vector<Ival> v;
+    v.reserve(g.n.size());
+    if (have) v = *have;
+    const size_t first = v.size();
+    v.resize(g.n.size());
+    for (size_t i = first; i < g.n.size(); i++) {        // children are interned before their parents
         const DNode &d = g.n[i];
         const Ival a = d.a >= 0 ? v[d.a] : Ival{0, 0, false};
         const Ival b = d.b >= 0 ? v[d.b] : Ival{0, 0, false};
@@ -770,6 +775,7 @@ struct Lowerer {
     std::vector<int32_t> users_idx;             // are users_idx[users_off[i] .. users_off[i + 1])
     // membership by stamp instead of hash sets (the scheduler asks for the cone of every AND / OR it meets: chess lowers
     // in a tenth of the time): a node is in the set computed last iff its stamp equals the set's epoch
+    static constexpr uint32_t STAMP_OUT = 0xFFFFFFFFu;      // seen_stamp of a node outside the section, or scheduled
     std::vector<uint32_t> seen_stamp, cone_stamp;
     std::vector<std::pair<int32_t, int>> reach_stack;      // (reach(): node, operands walked)
     uint32_t seen_epoch = 0, cone_epoch = 0;
@@ -813,6 +819,7 @@ struct Lowerer {
         row_depth = 0;
         used_rowguards.clear();
         seen_stamp.assign(N, 0); cone_stamp.assign(N, 0);
+        for (size_t i = 0; i < N; i++) if (!in_section[i]) seen_stamp[i] = STAMP_OUT;
         seen_epoch = cone_epoch = 0;
         users_off.assign(N + 1, 0);
         for (size_t i = 0; i < N; i++) {
@@ -837,7 +844,8 @@ struct Lowerer {
     std::vector<int32_t> reach(int32_t root) {
         std::vector<int32_t> r;
         ++seen_epoch;
-        auto fresh = [&](int32_t v) { return v >= 0 && in_section[v] && !visited[v] && seen_stamp[v] != seen_epoch; };
+        // (seen_stamp[v] = STAMP_OUT while v is outside the section or scheduled: one load answers "in the section, unscheduled, not seen in this walk")
+        auto fresh = [&](int32_t v) { return v >= 0 && seen_stamp[v] < seen_epoch; };
         if (!fresh(root)) return r;
         reach_stack.clear();
         reach_stack.push_back({root, 0});
@@ -955,7 +963,7 @@ struct Lowerer {
                 if (sz >= MIN_REGION && sz > best) { best = sz; guard = gq; body = bq; r_body.swap(r); }
             }
             if (guard >= 0 && g.n[guard].op != D_CONST) {
-                visited[i] = 1;
+                visited[i] = 1; seen_stamp[i] = STAMP_OUT;
                 visit(guard, sec);
                 if (!visited[body]) {
                     // reach(body) now = what it was before the guard was scheduled, less the nodes scheduled since: a node that
@@ -981,7 +989,7 @@ struct Lowerer {
                 return;
             }
         }
-        visited[i] = 1;
+        visited[i] = 1; seen_stamp[i] = STAMP_OUT;
         int32_t c0 = d.a, c1 = d.b;
         bool h0 = c0 >= 0 && in_section[c0], h1 = c1 >= 0 && in_section[c1];
         if (h0 && h1 && su(c1) > su(c0)) std::swap(c0, c1);   // heavier sub-tree first
@@ -1173,6 +1181,7 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
     if (row_guards) g.reserve(4 * N0 + 1024);      // the row bounds grow the DAG about threefold
     const uint32_t folded_scene = g.folded;     // constant ops folded in the scene itself (the row bounds fold more)
     std::vector<int32_t> rowub;
+    std::vector<Ival> iv_known;                 // intervals of the DAG's first nodes, for the passes that follow its growth
     if (row_guards) {
         const std::vector<uint8_t> isb0 = bool_typing();
         const std::vector<Ival> iv0 = intervals(g);
@@ -1218,7 +1227,7 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         if (trace) rb.trace("x");
         if (opts.no_y_spans == 0) {
             const std::vector<uint8_t> isb1 = bool_typing();
-            const std::vector<Ival> iv1 = intervals(g);
+            const std::vector<Ival> iv1 = intervals(g, &iv0);
             const std::vector<Mono> mono_y = monotonicity(g, iv1, DEP_Y, D_Y);
             RowBounds rby(g, isb1, mono_y, iv1, DEP_Y, D_Y, D_YMIN, D_YMAX);
             // A lift that had to give up on some sub-expression (`lossy`: a y-only Step(Sin) of a pattern, say, bounded by
@@ -1257,7 +1266,8 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
                 else if (all_free) rowub[l.first] = -1;
             }
             if (trace) rby.trace("y");
-        }
+            iv_known = iv1;
+        } else iv_known = iv0;
         rowub.resize(g.n.size(), -1);
     }
     lap("row bounds");
@@ -1315,7 +1325,7 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
     L.isbool = bool_typing();
     L.rowub = rowub;
     {
-        const std::vector<Ival> iv = intervals(g);
+        const std::vector<Ival> iv = intervals(g, &iv_known);
         L.sin_bounded.assign(N, 0);
         for (size_t i = 0; i < N; i++) {
             if (!reach[i] || (g.n[i].op != MARAY_OP_SIN && g.n[i].op != MARAY_OP_STEPSIN)) continue;
