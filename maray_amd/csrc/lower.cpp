@@ -155,17 +155,50 @@ struct Dag {
     }
 };
 
+// uint64 -> node id, open addressing (values are stored + 1: 0 marks an empty slot)
+struct FlatMap64 {
+    std::vector<std::pair<uint64_t, int32_t>> t;
+    size_t used = 0;
+    static size_t mix(uint64_t k) { k *= 0x9e3779b97f4a7c15ULL; return (size_t)(k ^ (k >> 29)); }
+    void grow(size_t size) {
+        std::vector<std::pair<uint64_t, int32_t>> old(size);
+        old.swap(t);
+        for (const auto &e : old) {
+            if (!e.second) continue;
+            size_t at = mix(e.first) & (size - 1);
+            while (t[at].second) at = (at + 1) & (size - 1);
+            t[at] = e;
+        }
+    }
+    void reserve(size_t n) { size_t want = 1024; while (want < 2 * n) want *= 2; if (want > t.size()) grow(want); }
+    const int32_t *find(uint64_t k) const {
+        if (t.empty()) return nullptr;
+        const size_t mask = t.size() - 1;
+        for (size_t at = mix(k) & mask; t[at].second; at = (at + 1) & mask)
+            if (t[at].first == k) return &t[at].second;
+        return nullptr;
+    }
+    void put(uint64_t k, int32_t v) {               // k is not in the table
+        if (2 * (used + 1) > t.size()) grow(t.empty() ? 1024 : 2 * t.size());
+        const size_t mask = t.size() - 1;
+        size_t at = mix(k) & mask;
+        while (t[at].second) at = (at + 1) & mask;
+        t[at] = {k, v + 1};
+        used++;
+    }
+};
+
 // ---- symbolic evaluation -------------------------------------------------------
 struct SymEval {
     const Scene &s;
     Dag &g;
-    std::unordered_map<uint64_t, int32_t> memo;         // (expr, ctx) -> dag node
-    std::unordered_map<uint64_t, int32_t> var_memo;     // (ctx, def index) -> dag node
+    FlatMap64 memo;                                     // (expr, ctx) -> dag node
+    FlatMap64 var_memo;                                 // (ctx, def index) -> dag node
     std::unordered_set<uint64_t> in_progress;
     std::unordered_map<uint64_t, int32_t> id_node;      // Var id -> dag node at its use sites (Cache transparency)
     int depth = 0;
 
-    SymEval(const Scene &s_, Dag &g_) : s(s_), g(g_) {}
+    SymEval(const Scene &s_, Dag &g_) : s(s_), g(g_) { memo.reserve(s_.nodes.size()); }
 
     int32_t var(uint64_t id, int32_t ctx) {
         int32_t r = -1;
@@ -174,13 +207,12 @@ struct SymEval {
             for (size_t i = 0; i < c.ids.size(); i++) {
                 if (c.ids[i] != id) continue;                       // first match wins (src/cache.rs:32-33)
                 uint64_t k = ((uint64_t)(uint32_t)ctx << 32) | (uint32_t)i;
-                auto it = var_memo.find(k);
-                if (it != var_memo.end()) { r = it->second; break; }
+                if (const int32_t *hit = var_memo.find(k)) { r = *hit - 1; break; }
                 if (!in_progress.insert(k).second)
                     throw Error{MARAY_E_CYCLE, "Let variable " + std::to_string(id) + " is defined in terms of itself"};
                 r = eval(c.defs[i], ctx);                            // definitions see their own Let's ctx (src/cache.rs:34)
                 in_progress.erase(k);
-                var_memo.emplace(k, r);
+                var_memo.put(k, r);
                 break;
             }
         }
@@ -194,8 +226,7 @@ struct SymEval {
 
     int32_t eval(int32_t e, int32_t ctx) {
         uint64_t key = ((uint64_t)(uint32_t)e << 32) | (uint32_t)(ctx + 1);
-        auto it = memo.find(key);
-        if (it != memo.end()) return it->second;
+        if (const int32_t *hit = memo.find(key)) return *hit - 1;
         if (++depth > 2000000) throw Error{MARAY_E_LIMIT, "expression too deep"};
         const Node &n = s.nodes[e];
         int32_t r;
@@ -225,7 +256,7 @@ struct SymEval {
             }
         }
         depth--;
-        memo.emplace(key, r);
+        memo.put(key, r);
         return r;
     }
 };
@@ -397,6 +428,22 @@ std::vector<Mono> monotonicity(const Dag &g, const std::vector<Ival> &iv, uint8_
 // A monotone boolean takes its extreme values at the ends of the span (monotone on the domain is monotone on any
 // sub-interval).  Applied to x with lo / hi = XMIN / XMAX it gives the row guards; applied once more, to y with
 // YMIN / YMAX, to those guards, it gives guards that hold over a rectangle of pixels.
+// A map keyed by DAG node ids (dense, growing): a vector and a presence byte per id (the memo tables of the passes below were
+// node-based hash maps: a tenth of a large scene's lowering)
+template <class T> struct IdMap {
+    std::vector<T> v;
+    std::vector<uint8_t> has;
+    std::vector<int32_t> keys;
+    const T *find(int32_t k) const { return (size_t)k < has.size() && has[k] ? &v[k] : nullptr; }
+    void put(int32_t k, const T &x) {
+        if ((size_t)k >= has.size()) { const size_t n = std::max<size_t>(2 * has.size(), (size_t)k + 1024); v.resize(n); has.resize(n, 0); }
+        if (!has[k]) keys.push_back(k);
+        has[k] = 1; v[k] = x;
+    }
+    void clear() { for (int32_t k : keys) has[k] = 0; keys.clear(); }
+    void reserve(size_t n) { if (n > has.size()) { v.resize(n); has.resize(n, 0); } }
+};
+
 struct RowBounds {
     struct B { int32_t ub, lb; bool lossy; };       // lossy: somewhere below, a sub-expression could only be bounded by "anything"
     Dag &g;
@@ -404,31 +451,31 @@ struct RowBounds {
     const std::vector<Mono> &mono;
     const std::vector<Ival> &range;                 // static interval of every node over the whole domain
     const uint8_t dep_bit, var_leaf;
-    std::unordered_map<uint64_t, int32_t> sub_memo;
-    std::unordered_map<int32_t, B> memo;
+    IdMap<int32_t> sub_lo, sub_hi;                   // subst(i, x0), subst(i, xmax)
+    IdMap<B> memo;
     struct IV { int32_t lo, hi; bool ok() const { return lo >= 0; } };
-    std::unordered_map<int32_t, IV> iv_memo;
+    IdMap<IV> iv_memo;
     int32_t c_true, c_false, x0, xmax;
 
     RowBounds(Dag &g_, const std::vector<uint8_t> &b, const std::vector<Mono> &m, const std::vector<Ival> &rg, uint8_t dep_bit_, uint8_t var_leaf_,
               uint8_t lo_leaf, uint8_t hi_leaf)
         : g(g_), isbool(b), mono(m), range(rg), dep_bit(dep_bit_), var_leaf(var_leaf_) {
-        sub_memo.reserve(2 * g.n.size()); memo.reserve(g.n.size()); iv_memo.reserve(g.n.size());
+        sub_lo.reserve(2 * g.n.size()); sub_hi.reserve(2 * g.n.size()); memo.reserve(2 * g.n.size()); iv_memo.reserve(2 * g.n.size());
         c_true = g.konst(1.0); c_false = g.konst(0.0); x0 = g.leaf(lo_leaf); xmax = g.leaf(hi_leaf);
     }
     int32_t subst(int32_t i, int32_t xr) {          // i with the coordinate replaced by node xr
         const DNode d = g.n[i];
         if (!(d.dep & dep_bit)) return i;
         if (d.op == var_leaf) return xr;
-        const uint64_t key = ((uint64_t)(uint32_t)i << 32) | (uint32_t)xr;
-        auto it = sub_memo.find(key);
-        if (it != sub_memo.end()) return it->second;
+        IdMap<int32_t> &sub_memo = xr == x0 ? sub_lo : sub_hi;          // (the coordinate is only ever replaced by one of the span's ends)
+        if (xr != x0 && xr != xmax) throw Error{MARAY_E_INTERNAL, "subst: not an end of the span"};
+        if (const int32_t *hit = sub_memo.find(i)) return *hit;
         int32_t r;
         if (d.b >= 0) {
             const int32_t a = subst(d.a, xr), b = subst(d.b, xr);
             r = d.op == MARAY_OP_APP ? g.app(d.aux, a, b) : g.binary(d.op, a, b);
         } else r = g.unary(d.op, subst(d.a, xr));
-        sub_memo.emplace(key, r);
+        sub_memo.put(i, r);
         return r;
     }
     int32_t b_not(int32_t a) { return g.binary(MARAY_OP_ADD, c_true, g.unary(MARAY_OP_NEG, a)); }
@@ -443,8 +490,7 @@ struct RowBounds {
         const DNode d = g.n[i];
         if (!(d.dep & dep_bit)) return {i, i};
         if (d.op == var_leaf) return {x0, xmax};
-        auto it = iv_memo.find(i);
-        if (it != iv_memo.end()) return it->second;
+        if (const IV *hit = iv_memo.find(i)) return *hit;
         IV r{-1, -1};
         const Mono m = (size_t)i < mono.size() ? mono[i] : M_NONE;
         const bool clean = (size_t)i < range.size() && !range[i].nan;
@@ -506,7 +552,7 @@ struct RowBounds {
             if (r.ok() && d.op < MARAY_OP_COUNT) fired[d.op]++;
         }
         else if (r.ok()) fired_mono++;
-        iv_memo.emplace(i, r);
+        iv_memo.put(i, r);
         return r;
     }
     // which rules produced an interval (MARAY_TRACE_LOWER=1 prints them: what a fuzz family reaches)
@@ -525,14 +571,13 @@ struct RowBounds {
     // sign-clear factor keeps it (+0 * c = +0); max, min and sum of sign-clear values combine their operands' (all
     // operands +0 => +0).  c_true = no such statement.  `clear[i]`: the static analysis proves i NaN-free with its
     // sign bit clear, `finite[i]`: and below +inf.
-    std::unordered_map<int32_t, int32_t> z_memo;
+    IdMap<int32_t> z_memo;
     int32_t zub(int32_t i, const std::vector<uint8_t> &clear, const std::vector<uint8_t> &finite) {
         if (i < 0 || (size_t)i >= isbool.size()) return c_true;
         if (isbool[i]) return bounds(i).ub;
         const DNode d = g.n[i];
         if (!(d.dep & dep_bit) || d.a < 0 || d.b < 0 || !clear[i]) return c_true;
-        auto it = z_memo.find(i);
-        if (it != z_memo.end()) return it->second;
+        if (const int32_t *hit = z_memo.find(i)) return *hit;
         int32_t r = c_true;
         const int32_t za = zub(d.a, clear, finite), zb = zub(d.b, clear, finite);
         switch (d.op) {
@@ -554,7 +599,7 @@ struct RowBounds {
             break;
         default: break;
         }
-        z_memo.emplace(i, r);
+        z_memo.put(i, r);
         return r;
     }
 
@@ -562,8 +607,7 @@ struct RowBounds {
         if ((size_t)i >= isbool.size() || !isbool[i]) return {c_true, c_false, true};
         const DNode d = g.n[i];
         if (!(d.dep & dep_bit)) return {i, i, false};
-        auto it = memo.find(i);
-        if (it != memo.end()) return it->second;
+        if (const B *hit = memo.find(i)) return *hit;
         B r{c_true, c_false, true};
         const Mono m = (size_t)i < mono.size() ? mono[i] : M_NONE;
         if (m == M_INC || m == M_DEC || m == M_MONO) {
@@ -585,7 +629,7 @@ struct RowBounds {
             const IV a = ival(d.a);
             if (a.ok()) r = {g.unary(MARAY_OP_STEP, a.hi), g.unary(MARAY_OP_STEP, a.lo), false};
         }
-        memo.emplace(i, r);
+        memo.put(i, r);
         return r;
     }
 };
@@ -678,7 +722,9 @@ struct Privatizer {
     std::vector<int32_t> &rowub;
     std::vector<uint8_t> is_root, seen;
     std::vector<int32_t> remap;                      // original node -> node after privatisation (-2: not yet)
-    std::unordered_map<int32_t, int32_t> memo;       // clones of the region being copied
+    IdMap<int32_t> memo;                             // clones of the region being copied
+    mutable std::vector<uint32_t> cone_stamp;        // x_cone: the walk a node was last counted in
+    mutable uint32_t cone_epoch = 0;
     uint32_t inst = 0;
     size_t budget;
 
@@ -688,14 +734,17 @@ struct Privatizer {
     bool x_op(int32_t i) const { return i >= 0 && g.n[i].op < D_CONST && (g.n[i].dep & DEP_X); }
 
     size_t x_cone(int32_t root, size_t cap) const {  // x-dependent ops below root (root included), counted up to cap
-        std::unordered_set<int32_t> in;
+        if (cone_stamp.size() < g.n.size()) cone_stamp.resize(g.n.size(), 0);
+        ++cone_epoch;
+        size_t in = 0;
         std::vector<int32_t> st{root};
-        while (!st.empty() && in.size() <= cap) {
+        while (!st.empty() && in <= cap) {
             const int32_t v = st.back(); st.pop_back();
-            if (!x_op(v) || !in.insert(v).second) continue;
+            if (!x_op(v) || cone_stamp[v] == cone_epoch) continue;
+            cone_stamp[v] = cone_epoch; in++;
             st.push_back(g.n[v].a); st.push_back(g.n[v].b);
         }
-        return in.size();
+        return in;
     }
     void select(int32_t i) {                         // outermost bounded conjunctions, seen from the channel roots
         if (!x_op(i) || seen[i]) return;
@@ -708,14 +757,13 @@ struct Privatizer {
     }
     int32_t clone(int32_t i) {
         if (!x_op(i)) return i;                      // leaves, constants and y-only values stay shared
-        auto it = memo.find(i);
-        if (it != memo.end()) return it->second;
+        if (const int32_t *hit = memo.find(i)) return *hit;
         DNode d = g.n[i];
         if (d.a >= 0) d.a = clone(d.a);
         if (d.b >= 0) d.b = clone(d.b);
         d.inst = inst;
         const int32_t r = g.intern(d);
-        memo.emplace(i, r);
+        memo.put(i, r);
         return r;
     }
     int32_t map(int32_t i) {
