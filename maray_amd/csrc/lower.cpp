@@ -823,9 +823,14 @@ struct Lowerer {
     std::vector<int32_t> users_idx;             // are users_idx[users_off[i] .. users_off[i + 1])
     // membership by stamp instead of hash sets (the scheduler asks for the cone of every AND / OR it meets: chess lowers
     // in a tenth of the time): a node is in the set computed last iff its stamp equals the set's epoch
-    static constexpr uint32_t STAMP_OUT = 0xFFFFFFFFu;      // seen_stamp of a node outside the section, or scheduled
-    std::vector<uint32_t> seen_stamp, cone_stamp;
+    static constexpr uint32_t STAMP_OUT = 0xFFFFFFFFu;      // stamp of a node outside the section, or scheduled
+    // what reach() reads of a node, twelve bytes instead of the DAG's forty: its operands inside the section (-1: none or outside)
+    // and the walk it was last seen in -- the walks are bound by memory, and a large scene's DAG does not fit the cache the nodes' links do
+    struct Link { int32_t a, b; uint32_t stamp; };
+    std::vector<Link> link;
+    std::vector<uint32_t> cone_stamp;
     std::vector<std::pair<int32_t, int>> reach_stack;      // (reach(): node, operands walked)
+    std::vector<int32_t> reach_buf;
     uint32_t seen_epoch = 0, cone_epoch = 0;
     bool in_cone(int32_t v) const { return cone_stamp[v] == cone_epoch; }
     std::unordered_map<uint64_t, uint32_t> const_index;
@@ -866,8 +871,12 @@ struct Lowerer {
         visited.assign(N, 0);
         row_depth = 0;
         used_rowguards.clear();
-        seen_stamp.assign(N, 0); cone_stamp.assign(N, 0);
-        for (size_t i = 0; i < N; i++) if (!in_section[i]) seen_stamp[i] = STAMP_OUT;
+        cone_stamp.assign(N, 0);
+        link.resize(N);
+        for (size_t i = 0; i < N; i++) {
+            const int32_t a = g.n[i].a, b = g.n[i].b;
+            link[i] = Link{a >= 0 && in_section[a] ? a : -1, b >= 0 && in_section[b] ? b : -1, in_section[i] ? 0u : STAMP_OUT};
+        }
         seen_epoch = cone_epoch = 0;
         users_off.assign(N + 1, 0);
         for (size_t i = 0; i < N; i++) {
@@ -890,26 +899,26 @@ struct Lowerer {
     // node -- and are sets, so any such order gives the same cone; sorting the nodes by id (ascending ids are one such
     // order) was an eighth of a large scene's lowering.
     std::vector<int32_t> reach(int32_t root) {
-        std::vector<int32_t> r;
         ++seen_epoch;
-        // (seen_stamp[v] = STAMP_OUT while v is outside the section or scheduled: one load answers "in the section, unscheduled, not seen in this walk")
-        auto fresh = [&](int32_t v) { return v >= 0 && seen_stamp[v] < seen_epoch; };
-        if (!fresh(root)) return r;
+        // (stamp = STAMP_OUT while a node is outside the section or scheduled: one load answers "in the section, unscheduled, not seen in this walk")
+        auto fresh = [&](int32_t v) { return v >= 0 && link[v].stamp < seen_epoch; };
+        if (!fresh(root)) return {};
+        reach_buf.clear();                  // (collected in a buffer that keeps its capacity: the result is allocated once, at its size)
         reach_stack.clear();
         reach_stack.push_back({root, 0});
-        seen_stamp[root] = seen_epoch;
+        link[root].stamp = seen_epoch;
         while (!reach_stack.empty()) {
             auto &top = reach_stack.back();
             const int32_t v = top.first;
             if (top.second < 2) {
-                const int32_t c = top.second++ == 0 ? g.n[v].a : g.n[v].b;
-                if (fresh(c)) { seen_stamp[c] = seen_epoch; reach_stack.push_back({c, 0}); }
+                const int32_t c = top.second++ == 0 ? link[v].a : link[v].b;
+                if (fresh(c)) { link[c].stamp = seen_epoch; reach_stack.push_back({c, 0}); }
                 continue;
             }
-            r.push_back(v);
+            reach_buf.push_back(v);
             reach_stack.pop_back();
         }
-        return r;
+        return std::vector<int32_t>(reach_buf.begin(), reach_buf.end());
     }
 
     // The exclusive cone of `body` with respect to its consumer `n`: the nodes of reach(body) that
@@ -1011,7 +1020,7 @@ struct Lowerer {
                 if (sz >= MIN_REGION && sz > best) { best = sz; guard = gq; body = bq; r_body.swap(r); }
             }
             if (guard >= 0 && g.n[guard].op != D_CONST) {
-                visited[i] = 1; seen_stamp[i] = STAMP_OUT;
+                visited[i] = 1; link[i].stamp = STAMP_OUT;
                 visit(guard, sec);
                 if (!visited[body]) {
                     // reach(body) now = what it was before the guard was scheduled, less the nodes scheduled since: a node that
@@ -1037,7 +1046,7 @@ struct Lowerer {
                 return;
             }
         }
-        visited[i] = 1; seen_stamp[i] = STAMP_OUT;
+        visited[i] = 1; link[i].stamp = STAMP_OUT;
         int32_t c0 = d.a, c1 = d.b;
         bool h0 = c0 >= 0 && in_section[c0], h1 = c1 >= 0 && in_section[c1];
         if (h0 && h1 && su(c1) > su(c0)) std::swap(c0, c1);   // heavier sub-tree first
