@@ -188,26 +188,21 @@ uint64_t scene_node_count(const Scene &s, int c) { return count_rec(s, s.color[c
 // output scene, so structural equality is index equality.
 namespace {
 
-struct PlainKey {                       // a node without context or tokens: five words (the common case by far)
-    uint64_t f[5];
-    bool operator==(const PlainKey &o) const { return memcmp(f, o.f, sizeof f) == 0; }
-};
-struct PlainKeyHash {
-    size_t operator()(const PlainKey &k) const {
-        uint64_t h = 0x9e3779b97f4a7c15ull;
-        for (uint64_t w : k.f) { h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 32; }
-        return (size_t)h;
-    }
-};
-
 struct Interner {
     Scene &out;
     std::unordered_map<std::string, int32_t> map;             // Let / Decor nodes: the key spells out their context / tokens
-    // plain nodes: open addressing over (key, node id + 1) -- a tenth of a large scene's lowering was this table as a node-based map
-    std::vector<std::pair<PlainKey, int32_t>> plain;
+    // plain nodes: open addressing over node ids + 1 (a slot's key is read from the node it names; four bytes a slot: the
+    // table of a large scene stays in the cache) -- a tenth of a large scene's lowering was this table as a node-based map
+    std::vector<int32_t> plain;
     size_t n_plain = 0;
 
     static void put(std::string &k, uint64_t v) { k.append((const char *)&v, 8); }
+    static size_t hash_plain(const Node &n) {
+        uint64_t h = 0x9e3779b97f4a7c15ull;
+        for (uint64_t w : {(uint64_t)n.tag, n.u, (uint64_t)n.app, (uint64_t)(int64_t)n.a, (uint64_t)(int64_t)n.b}) { h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 32; }
+        return (size_t)h;
+    }
+    static bool same_plain(const Node &x, const Node &y) { return x.tag == y.tag && x.u == y.u && x.app == y.app && x.a == y.a && x.b == y.b; }
 
     void reserve_plain(size_t nodes) {
         size_t want = 1024;
@@ -215,26 +210,25 @@ struct Interner {
         if (want > plain.size()) rehash(want);
     }
     void rehash(size_t size) {
-        std::vector<std::pair<PlainKey, int32_t>> old(size);
+        std::vector<int32_t> old(size, 0);
         old.swap(plain);
-        for (const auto &e : old) {
-            if (!e.second) continue;
-            size_t at = PlainKeyHash()(e.first) & (size - 1);
-            while (plain[at].second) at = (at + 1) & (size - 1);
+        for (int32_t e : old) {
+            if (!e) continue;
+            size_t at = hash_plain(out.nodes[e - 1]) & (size - 1);
+            while (plain[at]) at = (at + 1) & (size - 1);
             plain[at] = e;
         }
     }
 
     int32_t intern(const Node &n, const Ctx *ctx, const std::vector<Token> *toks) {
         if (!ctx && !toks) {
-            const PlainKey pk{{n.tag, n.u, n.app, (uint64_t)(int64_t)n.a, (uint64_t)(int64_t)n.b}};
             if (2 * (n_plain + 1) > plain.size()) rehash(plain.empty() ? 1024 : 2 * plain.size());
             const size_t mask = plain.size() - 1;
-            size_t at = PlainKeyHash()(pk) & mask;
-            for (; plain[at].second; at = (at + 1) & mask)
-                if (plain[at].first == pk) return plain[at].second - 1;
+            size_t at = hash_plain(n) & mask;
+            for (; plain[at]; at = (at + 1) & mask)
+                if (same_plain(out.nodes[plain[at] - 1], n)) return plain[at] - 1;
             const int32_t id = out.add(n);
-            plain[at] = {pk, id + 1};
+            plain[at] = id + 1;
             n_plain++;
             return id;
         }
