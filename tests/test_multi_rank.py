@@ -129,11 +129,12 @@ def test_bench_starts_its_own_ranks_and_fails_loudly_without_a_device():
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and '{' not in r.stdout
-    assert r.stderr.count('no HIP device is visible') == 2 and '2-rank run failed' in r.stderr
+    # (a rank that fails ends the run: the launcher stops the other one, which may not have got as far as its own message)
+    assert 1 <= r.stderr.count('no HIP device is visible') <= 2 and '2-rank run failed' in r.stderr
     # an environment that exports WORLD_SIZE=1 to everything is not a launcher: the parent still starts its own ranks
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
                        capture_output=True, text=True, env=dict(env, WORLD_SIZE='1'), timeout=300)
-    assert r.returncode != 0 and r.stderr.count('no HIP device is visible') == 2 and '2-rank run failed' in r.stderr
+    assert r.returncode != 0 and 1 <= r.stderr.count('no HIP device is visible') <= 2 and '2-rank run failed' in r.stderr
     # a rank count that does not match --gpus is refused rather than printed as something else
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0'],
                        capture_output=True, text=True, env=dict(env, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0'), timeout=300)
