@@ -619,7 +619,11 @@ struct Emitter {
                 if (it != texels.end()) { in_scope = it->second.second == 0; for (const Open &o : open) in_scope |= o.id == it->second.second; }
                 if (!in_scope) {
                     const std::string tn = "mr_tx" + std::to_string(i);
-                    out += "    const " + std::string(td == "mr_d" ? "mr_tx4 " : r.wide ? "mr_tx2 " : "mr_tx ") + tn + " = mr_texel(mr_t" + std::to_string(aux / 5u) + ", tex, " + ax + ", " + ay + ");\n";
+                    // (four pixels per lane: both coordinates may be numbers that are not typed mr_d -- a constant and a y value, say: the texel is
+                    // then the same for the four pixels, and without the conversions the call would resolve to the scalar form)
+                    const bool four = td == "mr_d";
+                    out += "    const " + std::string(four ? "mr_tx4 " : r.wide ? "mr_tx2 " : "mr_tx ") + tn + " = mr_texel(mr_t" + std::to_string(aux / 5u) + ", tex, " +
+                           (four ? "mr_d(" + ax + "), mr_d(" + ay + ")" : ax + ", " + ay) + ");\n";
                     it = texels.insert_or_assign(key, std::make_pair(tn, open.empty() ? 0u : open.back().id)).first;
                 }
                 e = "mr_texch(" + it->second.first + ", " + std::to_string(aux % 5u) + "u)";

@@ -106,3 +106,27 @@ def transforms(size):
     body = var_offset(let_([(u[1], back[0])], mul(clamp_unit(u), nat(255))), 7)
     assert var_range(body) == [u[1] + 7, u[1] + 8]
     return [r, g, body]
+
+
+def ops_on_a_guarded_mask(w, h):
+    """Every kind of op fed with the VALUE of guarded shapes (textured triangles, each behind a rectangle guard), directly and
+    through arithmetic with constants: in the specialised kernel's variant for tiles without a guard bit those values are the
+    literal 0.0, so every op there meets operands that are numbers, not vector values — texture coordinates included (a
+    random scene of round 4's second GPU sweep, seed 6462, was the first to do that to an App: its four-wide form did not
+    compile).  Two textures (ids 0..4 and 5..9)."""
+    from fuzz_scenes import subst_xy
+    from marayb import chess, inside_triangle, min_, recip, step, to_uv
+    p = [x(), y()]
+    masks = []
+    for pts in ([(w // 8, h // 8), (w // 2, h // 6), (w // 5, h - h // 8)], [(w // 2, h // 3), (w - w // 8, h // 8), (w - w // 6, h - h // 6)],
+                [(w // 3, h - h // 3), (w // 2 + w // 8, h // 2), (w // 2, h - h // 10)]):
+        pts = [(nat(a), nat(b)) for a, b in pts]
+        uv = to_uv(pts, [(nat(0), nat(0)), (nat(1), nat(0)), (nat(0), nat(1))], p)
+        masks.append(min_(inside_triangle(pts, p), subst_xy(chess(4), uv[0], uv[1])))
+    m0, m1, m2 = masks
+    c0 = add(add(abs_(sub(m0, div(nat(1), nat(2)))), recip(add(m1, nat(1)))), add(sqrt(m2), mul(sin(m0), exp(m1))))
+    c0 = add(c0, add(ln(add(m2, nat(1))), add(step(sub(m0, div(nat(1), nat(2)))), step(sin(mul(m1, nat(3)))))))
+    c1 = add(app(channel(0, 1), mul(m0, nat(20)), y()), add(app(channel(1, 0), x(), mul(m1, nat(9))), app(channel(0, 2), m2, mul(m0, nat(3)))))
+    c1 = add(c1, add(app(channel(1, 2), mul(m2, nat(7)), mul(y(), div(nat(1), nat(2)))), neg(m1)))
+    c2 = max_(mul(max_(max_(m0, m1), m2), nat(255)), add(mul(sqrt(add(m0, m1)), nat(40)), mul(x(), div(nat(1), nat(8)))))
+    return [mul(c0, nat(30)), mul(c1, div(nat(1), nat(2))), c2]

@@ -569,6 +569,21 @@ def test_textured_scene(chess_bytes, monkeypatch):
             monkeypatch.delenv(k)
 
 
+def test_ops_on_the_value_of_guarded_shapes(monkeypatch):
+    """scenes.ops_on_a_guarded_mask: every kind of op, texture lookups included, fed with the value of guarded shapes -- literal
+    zeros in the specialised kernel's variant for tiles without a guard bit (tests/test_jit_offline.py has the build): every
+    evaluator against the oracle on every pixel, the specialised kernel also two rows per wavefront and one texel per App."""
+    tex = scenes.textures(scale=8)
+    data = encode((512, 256), scenes.ops_on_a_guarded_mask(512, 256))
+    gpu_vs_oracle(data, 512, 256, [(0, 256)], textures=tex)
+    for env in ({'MARAY_JIT_ROWS2': '1'}, {'MARAY_JIT_TEXEL_ONCE': '0'}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        gpu_vs_oracle(data, 512, 256, [(0, 256)], textures=tex, backends=[M.BACKEND_JIT])
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_texel_addressing_inside_outside_and_on_a_very_tall_image():
     """`fun_color_channel` (/root/reference/src/textures.rs:27-36) around every border: coordinates below zero, exactly on the last
     texel, one past it, far past it, NaN (0/0 on one row) and +-inf (1/0), for a small image and for one that is 2^24 + 5 texels

@@ -107,6 +107,26 @@ def test_random_scenes_build():
     assert built >= 35
 
 
+def test_ops_on_literal_operands_build_in_every_form(monkeypatch):
+    """In the variant for tiles without a guard bit the value of every guarded shape is the literal 0.0: ops meet operands
+    that are numbers, not vector values -- texture coordinates too (seed 6462 of round 4's second GPU sweep: `mr_texel(t, tex,
+    0.0, yv[2])` resolved to the one-pixel form inside the four-pixel variant and the kernel did not compile).  The crafted
+    scene does that to every kind of op; both builds with one and with two rows per wavefront."""
+    import re
+    from test_fuzz import lowered
+    tape = M.Scene(encode((512, 256), scenes.ops_on_a_guarded_mask(512, 256))).lower()
+    text, _ = build(tape)
+    sky = text[text.index('mr_d o0 = 0.0'):]
+    sky = sky[:sky.index('mr_u3')]
+    assert 'mr_texel(mr_t0, tex, mr_d(0.0), mr_d(0.0))' in sky and len(re.findall(r'mr_texel\(', sky)) == 4
+    assert 'mr_stepsin_bounded_m(0.0)' in sky and 'mr_ln(1.0)' in sky
+    _, tape2 = lowered(6462, 2)
+    build(tape2)
+    monkeypatch.setenv('MARAY_JIT_ROWS2', '1')
+    build(tape)
+    build(tape2)
+
+
 def test_code_key_is_remembered_under_the_programs_name(chess_bytes, tmp_path, monkeypatch):
     """The code key hashes the generated sources (0.1 s for chess); it is remembered under a hash of the program, the
     library's build and the MARAY_JIT_* knobs, in the process and in <cache>/<name>.key.  A knob that changes the source
