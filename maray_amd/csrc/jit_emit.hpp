@@ -618,7 +618,7 @@ struct Emitter {
                 bool in_scope = false;
                 if (it != texels.end()) { in_scope = it->second.second == 0; for (const Open &o : open) in_scope |= o.id == it->second.second; }
                 if (!in_scope) {
-                    const std::string tn = "mr_tx" + std::to_string(i);
+                    const std::string tn = "mr_tl" + std::to_string(i);          // (not mr_tx<i>: mr_tx2 and mr_tx4 are types -- seed 8157 of a compile sweep had its lookup at op 4)
                     // (four pixels per lane: both coordinates may be numbers that are not typed mr_d -- a constant and a y value, say: the texel is
                     // then the same for the four pixels, and without the conversions the call would resolve to the scalar form)
                     const bool four = td == "mr_d";

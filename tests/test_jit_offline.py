@@ -122,9 +122,11 @@ def test_ops_on_literal_operands_build_in_every_form(monkeypatch):
     assert 'mr_stepsin_bounded_m(0.0)' in sky and 'mr_ln(1.0)' in sky
     _, tape2 = lowered(6462, 2)
     build(tape2)
+    _, tape3 = lowered(8157, 2)      # its texture lookup is op 4: the texel's variable was named mr_tx4, which is a type
+    build(tape3)
     monkeypatch.setenv('MARAY_JIT_ROWS2', '1')
-    build(tape)
-    build(tape2)
+    for t in (tape, tape2, tape3):
+        build(t)
 
 
 def test_code_key_is_remembered_under_the_programs_name(chess_bytes, tmp_path, monkeypatch):
