@@ -21,8 +21,12 @@ using namespace maray;
 
 struct maray_scene {
     Scene s;
-    // 128-bit hash of the scene's encoding (what `save` would write): the name maray_gen_to_image remembers a scene's
-    // tape and contexts under.  Computed on first use, dropped by every call that changes the scene.
+    // 128-bit name of the scene's program: what maray_gen_to_image remembers a scene's tape and contexts under.  A scene read from
+    // bytes is named by the hash of those bytes (without the header: the size is not part of a program); a rescale of a named
+    // scene folds its factors into the name (load, rescale, render is what the CLI and an embedding do: re-encoding 88,000
+    // nodes to name them cost the first call of chess 3-4 ms); every other call that changes the scene drops the name, and
+    // the next use hashes the scene's encoding (what `save` would write).  Two names for one program are a miss in the
+    // cache, nothing worse.
     std::mutex key_mutex;
     bool key_valid = false;
     uint64_t key[2] = {0, 0};
@@ -217,6 +221,14 @@ const char *maray_last_error(void) { return g_err.c_str(); }
 const char *maray_version(void) { return "maray_amd 0.1 (gfx950; tape v2; mirrors maray 0.3.8)"; }
 
 // ---- scenes ------------------------------------------------------------------
+static void name_from_bytes(maray_scene *s, const uint8_t *buf, size_t len)
+{
+    std::lock_guard<std::mutex> lk(s->key_mutex);
+    s->key[0] = 0x6d61726179ull; s->key[1] = 3;
+    hash128(buf + (len >= 8 ? 8 : len), len >= 8 ? len - 8 : 0, s->key);
+    s->key_valid = true;
+}
+
 int maray_scene_from_bytes(const uint8_t *buf, size_t len, maray_scene **out)
 {
     return guard([&] {
@@ -225,6 +237,7 @@ int maray_scene_from_bytes(const uint8_t *buf, size_t len, maray_scene **out)
         maray_scene *s = new maray_scene();
         try { run_big_stack([&] { scene_decode(buf, len, s->s); }); }
         catch (...) { delete s; throw; }
+        name_from_bytes(s, buf, len);
         *out = s;
     });
 }
@@ -244,6 +257,7 @@ int maray_scene_open(const char *path, maray_scene **out)
         maray_scene *s = new maray_scene();
         try { run_big_stack([&] { scene_decode(b.data(), b.size(), s->s); }); }
         catch (...) { delete s; throw; }
+        name_from_bytes(s, b.data(), b.size());
         *out = s;
     });
 }
@@ -305,7 +319,12 @@ int maray_scene_fix_color(maray_scene *s)
 
 int maray_scene_rescale(maray_scene *s, uint32_t sx, uint32_t sy)
 {
-    return guard([&] { REQUIRE(s, "null argument"); s->key_valid = false; scene_rescale(s->s, sx, sy); });
+    return guard([&] {
+        REQUIRE(s, "null argument");
+        scene_rescale(s->s, sx, sy);
+        std::lock_guard<std::mutex> lk(s->key_mutex);
+        if (s->key_valid) { const uint32_t step[3] = {0x52455343u, sx, sy}; hash128(step, sizeof step, s->key); }      // "RESC", factors
+    });
 }
 
 int maray_scene_simplify(maray_scene *s)

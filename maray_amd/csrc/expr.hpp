@@ -66,6 +66,7 @@ void scene_decode(const uint8_t *buf, size_t len, Scene &out);            // thr
 void scene_encode(const Scene &s, std::vector<uint8_t> &out);            // current numbering
 uint64_t scene_node_count(const Scene &s, int c);
 void scene_fix_color(Scene &s);                                          // var_fixer::fix_color
+Scene scene_fixed(const Scene &s);                                       // the same into a new scene (the lowering's input stays as it is: no copy of an 88,000-node scene first)
 void scene_rescale(Scene &s, uint32_t sx, uint32_t sy);
 // simplify.cpp
 void scene_simplify(Scene &s, uint32_t flags = 0);                       // Expr::simplify on each channel (flags: MARAY_SIMPLIFY_*)

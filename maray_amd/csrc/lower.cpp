@@ -1194,9 +1194,7 @@ void lower_scene(const Scene &scene_in, const maray_lower_opts &opts, Tape &t)
         fprintf(stderr, "maray lower: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
-    Scene s = scene_in;
-    lap("copy scene");
-    scene_fix_color(s);
+    const Scene s = scene_fixed(scene_in);
     lap("fix_color");
 
     Dag g;

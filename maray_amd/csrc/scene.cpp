@@ -336,16 +336,21 @@ struct Fixer {
 
 }   // namespace
 
-void scene_fix_color(Scene &s)
+Scene scene_fixed(const Scene &s)
 {
-    if (s.fixed) return;
+    if (s.fixed) return s;
     Scene out;
     out.w = s.w; out.h = s.h; out.legacy = s.legacy;
     Fixer f(s, out);                      // one VarFixer for all three channels (:76)
     Renames empty;
     for (int c = 0; c < 3; c++) out.color[c] = f.fix(s.color[c], empty);
     out.fixed = true;
-    s = std::move(out);
+    return out;
+}
+
+void scene_fix_color(Scene &s)
+{
+    if (!s.fixed) s = scene_fixed(s);
 }
 
 // --------------------------------------------------------------- rescale ----
