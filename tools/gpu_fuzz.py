@@ -26,7 +26,7 @@ for seed in range(lo, hi):
     t = tex if n_tex else None
     want8, want64 = OScene(data).render_rows(W, H, 0, H, t)
     guarded += tape_eval.guards_reading_y(tape)[0] > 0
-    for b in (M.BACKEND_JIT, M.BACKEND_TAPE_SMEM):
+    for b in ((M.BACKEND_JIT, M.BACKEND_TAPE_SMEM, M.BACKEND_TAPE) if os.environ.get('MARAY_FUZZ_ALL_BACKENDS') == '1' else (M.BACKEND_JIT, M.BACKEND_TAPE_SMEM)):
         ctx = M.Context(tape, textures=t, backend=b)
         got8, got64 = ctx.render_rows(W, H, 0, H)
         ctx.close()
