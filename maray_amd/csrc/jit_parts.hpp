@@ -15,7 +15,10 @@ namespace maray {
 // conditions throughout (lane masks tested on the scalar unit), and the branch table of a guarded OR-reduction (an asm
 // goto inside a loop) only survives when the structurizer leaves uniform regions alone: without the option the back end
 // rewrites the table's edges into tests of flags nobody sets
-static const char JIT_OPTIONS[] = "--offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -std=c++17 -mllvm -structurizecfg-skip-uniform-regions";
+// -O2, not -O3: the two differ in a handful of instructions of chess's PIXEL kernel (170 lines of 13,000 of disassembly) and in nothing
+// measurable at run time (frame 27.2 / 27.2 us, config 3b 163-172 / 163-166, config 5 39.1 / 39.1), and -O2 builds that kernel -- the
+// long pole of a cold start: the ROW kernel takes as long either way -- a quarter faster: cold ctx_ms 1.68-1.73 -> 1.28-1.38 s
+static const char JIT_OPTIONS[] = "--offload-arch=gfx950 -O2 -ffp-contract=off -fno-fast-math -std=c++17 -mllvm -structurizecfg-skip-uniform-regions";
 
 static const uint32_t GW_INLINE_MAX = 12;       // up to this many guard words a rectangle's words are named SGPR pairs; beyond, they stay one per lane (v_readlane per test)
 static const unsigned ROW_BLOCK = 256;          // threads per block of the ROW kernel (64 ... 1024 move a chess frame by less than a microsecond)
